@@ -1,0 +1,211 @@
+/*
+ * takzero_hip.h — C ABI of libtakzero_hip.so, the MI355X (gfx950) engine for the
+ * takzero self-play / reanalyze hot path (batched MCTS + policy/value net forward).
+ *
+ * The reference (ViliamVadocz/takzero) has no FFI of its own for this path: its seams are
+ * the Rust traits `Agent` (takzero/src/search/agent.rs:5-14), `Network`
+ * (takzero/src/network/mod.rs:10-45) and the struct `BatchedMCTS`
+ * (takzero/src/search/node/batched.rs:24-409).  Every entry point below names the
+ * reference item it replaces.  A Rust adapter maps these calls back
+ * onto the reference's types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative TZ_E* code otherwise; the message
+ *     is available from tz_last_error() (thread local).
+ *   - caller owns every host buffer; the library owns device memory behind the handles.
+ *   - one handle is driven from one host thread (the reference is single threaded,
+ *     batched.rs:21-22); calls block until results are on the host unless noted.
+ *   - randomness never crosses the ABI: Dirichlet / Gumbel / opening choices are inputs
+ *     (the reference threads one StdRng through its calls; keeping the draws on the
+ *     caller side is the only way an adapter can reproduce its stream).
+ *   - moves are identified by the reference's policy index `move_index`
+ *     (takzero/src/network/repr.rs:49-71): channel * N*N + row * N + column.
+ *   - squares are indexed  sq = row * N + column  (row = rank-1, column = file).
+ */
+#ifndef TAKZERO_HIP_H
+#define TAKZERO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TZ_MAX_N 6
+#define TZ_MAX_SQUARES 36
+/* upper bound on legal moves in one position, per board size 3..6 (used to size rows) */
+#define TZ_MAX_ACTIONS 512
+
+/* error codes */
+#define TZ_OK 0
+#define TZ_EINVAL (-1)   /* bad argument (size, index, null)                           */
+#define TZ_EPARSE (-2)   /* malformed TPS / PTN / weight file                          */
+#define TZ_EDEVICE (-3)  /* HIP runtime failure (message carries hipGetErrorString)    */
+#define TZ_ENOMEM (-4)   /* host or device allocation failed                           */
+#define TZ_ECAPACITY (-5)/* a per-game node pool or trajectory buffer overflowed       */
+#define TZ_ESTATE (-6)   /* call not valid in the current state (e.g. noise on an      */
+                         /* un-expanded root — batched.rs / noise.rs:12-15 assert)     */
+#define TZ_ENUMERIC (-7) /* NaN produced by the net (reference panics: net5.rs:263)    */
+
+/* piece type of the top of a stack */
+#define TZ_EMPTY 0
+#define TZ_FLAT 1
+#define TZ_WALL 2
+#define TZ_CAP 3
+
+/* Eval tags, takzero/src/search/eval.rs:8-13 */
+#define TZ_EVAL_VALUE 0
+#define TZ_EVAL_WIN 1
+#define TZ_EVAL_LOSS 2
+#define TZ_EVAL_DRAW 3
+
+/* Terminal, takzero/src/search/env.rs:27-31 (from the side to move) */
+#define TZ_TERMINAL_NONE (-1)
+#define TZ_TERMINAL_WIN 0
+#define TZ_TERMINAL_LOSS 1
+#define TZ_TERMINAL_DRAW 2
+
+/*
+ * Packed game state = the fields of fast_tak::Game<N,HALF_KOMI> that the reference reads
+ * (repr.rs:169-228, env.rs:39-63).  Plain data, 376 bytes.
+ */
+typedef struct tz_state {
+    uint64_t colors[TZ_MAX_SQUARES]; /* bit i = colour of the i-th piece from the bottom (0 white, 1 black) */
+    uint8_t height[TZ_MAX_SQUARES];  /* number of pieces on the square                                     */
+    uint8_t top[TZ_MAX_SQUARES];     /* TZ_EMPTY / TZ_FLAT / TZ_WALL / TZ_CAP                               */
+    uint8_t stones[2];               /* remaining stones  [white, black]                                    */
+    uint8_t caps[2];                 /* remaining capstones [white, black]                                  */
+    uint8_t to_move;                 /* 0 white, 1 black                                                    */
+    uint8_t n;                       /* board size 3..6                                                     */
+    int8_t half_komi;                /* komi for black in half points (net5.rs:18 uses 4)                   */
+    uint8_t pad0;
+    uint16_t ply;
+    uint16_t reversible_plies;
+} tz_state;
+
+typedef struct tz_net tz_net;       /* opaque: a network on one GPU  (Network + Agent impl)   */
+typedef struct tz_search tz_search; /* opaque: BatchedMCTS<B, Game<N,HALF_KOMI>> on one GPU   */
+
+/* architectures (takzero/src/network/{net4_simhash,net5,net6_simhash}.rs) */
+#define TZ_ARCH_NET4_SIMHASH 4
+#define TZ_ARCH_NET5 5
+#define TZ_ARCH_NET6_SIMHASH 6
+/* test architecture: same graph as net5 on any board size with configurable depth, no RND/hash */
+#define TZ_ARCH_TEST 100
+
+/* arithmetic of the trunk */
+#define TZ_PREC_BF16 0 /* NHWC bf16 activations/weights, fp32 accumulate on MFMA (throughput path) */
+#define TZ_PREC_F32 1  /* fp32 everywhere (validation path for the 1e-3 logit gate)                 */
+
+/* built-in agents for tz_search_create (takzero/src/search/agent.rs:16-87) */
+#define TZ_AGENT_NET 0
+#define TZ_AGENT_DUMMY 1
+#define TZ_AGENT_SIMPLE 2
+
+const char* tz_last_error(void);
+int tz_version(void);
+int tz_device_count(void);
+
+/* ---------- text / index helpers (fast-tak / takparse formats) ---------- */
+int tz_state_from_tps(const char* tps, int n, int half_komi, tz_state* out);
+int tz_state_to_tps(const tz_state* s, char* buf, int buflen);
+int tz_move_to_ptn(int n, uint16_t move_index, char* buf, int buflen);
+int tz_move_from_ptn(int n, const char* ptn, uint16_t* move_index_out);
+/* number of policy logits for board size n: output_size::<N>(), repr.rs:119-121 */
+int tz_policy_size(int n);
+/* number of input planes: input_channels::<N>(), repr.rs:137-142 */
+int tz_input_channels(int n);
+
+/* ---------- Network lifecycle: Network::{new, load}  (network/mod.rs:10-35) ---------- */
+/* blocks = number of residual blocks for TZ_ARCH_TEST (ignored otherwise). */
+int tz_net_create(int board_n, int arch, int device_id, int precision, int blocks, tz_net** out);
+/* Flat weight container written by takzero_amd.weights (named fp32 tensors, state-dict
+ * names of the tch VarStore).  A failed load leaves the previous weights active
+ * (selfplay/src/main.rs:112-115). */
+int tz_net_load_weights(tz_net* net, const char* path);
+int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes);
+int tz_net_destroy(tz_net* net);
+
+/*
+ * Agent::policy_value_uncertainty  (agent.rs:5-14; net5.rs:220-285)
+ *   states[batch]; legal_idx[batch][amax] = move_index of each legal action in the caller's
+ *   order, legal_count[batch] <= amax.
+ *   logits_out[batch][amax]: raw logits of exactly those actions in that order (entries past
+ *   legal_count are 0); value_out[batch] in [-1,1] from the side to move;
+ *   variance_out[batch] in [0,4].  batch == 0 is TZ_EINVAL (net5.rs:226-227 asserts).
+ */
+int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* legal_idx,
+                const int32_t* legal_count, int amax, float* logits_out, float* value_out,
+                float* variance_out);
+/* Debug path: the input planes game_repr writes (repr.rs:169-228), NCHW fp32,
+ * planes_out[batch][channels*n*n], computed on the device by the same encoder. */
+int tz_net_encode(tz_net* net, int batch, const tz_state* states, float* planes_out);
+/* Full policy tensor [batch][policy_size] in the reference's NCHW flattening (net5.rs:238). */
+int tz_net_forward_raw(tz_net* net, int batch, const tz_state* states, float* policy_out,
+                       float* value_out, float* ube_out);
+
+/* ---------- BatchedMCTS (search/node/batched.rs:32-409) ---------- */
+/* BatchedMCTS::from_envs with default (empty-board) envs; node_capacity = node slots per game
+ * (0 = default).  net may be NULL when agent_kind != TZ_AGENT_NET. */
+int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int half_komi,
+                     int node_capacity, tz_search** out);
+int tz_search_destroy(tz_search* s);
+/* nodes_and_envs_mut: overwrite envs and reset their trees (reanalyze/src/main.rs:159-165). */
+int tz_search_set_positions(tz_search* s, int count, const int32_t* game_idx, const tz_state* states);
+int tz_search_get_positions(tz_search* s, tz_state* states_out /*[batch]*/);
+/* BatchedMCTS::new openings: env.rs:65-79.  opening_choice[g] in [0,16): symmetry*2 + opposite. */
+int tz_search_new_openings(tz_search* s, const int32_t* opening_choice);
+/* BatchedMCTS::simulate called n_sims times (batched.rs:63-128); betas[batch]. Asynchronous
+ * on the handle's stream; any later call that returns data synchronises. */
+int tz_search_simulate(tz_search* s, const float* betas, int n_sims);
+/* BatchedMCTS::apply_noise with caller-supplied Dirichlet samples (noise.rs:10-26):
+ * noise[batch][amax], row g holds one sample of dimension n_children(g). */
+int tz_search_apply_noise(tz_search* s, const float* noise, int amax, float ratio);
+/* per-root summary: evaluation, visit_count, std_dev, number of children, terminal flag */
+typedef struct tz_root_info {
+    uint32_t visit_count;
+    uint32_t n_children;
+    uint8_t eval_tag;
+    uint8_t is_terminal_env; /* env.terminal().is_some() */
+    uint16_t ply;
+    union { float value; uint32_t ply; } eval;
+    float std_dev;
+    float logit;
+    float probability;
+} tz_root_info;
+int tz_search_root_info(tz_search* s, tz_root_info* out /*[batch]*/);
+/* children of every root in fast-tak possible_moves order (callers zip by position:
+ * selfplay/src/main.rs:249-253).  Arrays are [batch][amax]; any pointer may be NULL. */
+int tz_search_root_children(tz_search* s, int amax, uint16_t* move_idx, uint32_t* visits,
+                            uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob,
+                            float* std_dev);
+/* Node::select_best_action per root (node/mod.rs:132-161). 0xFFFF for roots without children. */
+int tz_search_select_best_actions(tz_search* s, uint16_t* actions_out /*[batch]*/);
+/* Node::improved_policy(visitations) per root (policy.rs:23-48), [batch][amax]. */
+int tz_search_improved_policy(tz_search* s, float visitations, int amax, float* policy_out);
+/* Node::ube_target(beta) per root (node/mod.rs:215-230). */
+int tz_search_ube_target(tz_search* s, float beta, float* out /*[batch]*/);
+/* BatchedMCTS::step (batched.rs:131-144): descend (subtree reuse) + env.step; skipped for
+ * terminal roots.  actions[batch] are move indices. */
+int tz_search_step(tz_search* s, const uint16_t* actions);
+/* BatchedMCTS::restart_terminal_envs (batched.rs:185-203): finished games get a fresh opening
+ * (opening_choice as above) and a fresh tree; terminal_out[g] = TZ_TERMINAL_* of the game
+ * that ended, TZ_TERMINAL_NONE otherwise. */
+int tz_search_restart_terminal(tz_search* s, const int32_t* opening_choice, int8_t* terminal_out);
+/* BatchedMCTS::gumbel_sequential_halving with caller-supplied Gumbel(0,1) samples
+ * (batched.rs:207-409): gumbel[batch][amax]; selected_out[batch] move indices. */
+int tz_search_gumbel_sh(tz_search* s, const float* betas, int sampled_actions, int search_budget,
+                        const float* gumbel, int amax, uint16_t* selected_out);
+/* counters since creation: simulations (incl. Known hits) and network-evaluated leaves */
+int tz_search_counters(tz_search* s, uint64_t* simulations, uint64_t* nn_leaf_evals);
+int tz_search_sync(tz_search* s);
+/* time spent (ms, HIP events on the handle's stream) in the dominant conv kernel and its
+ * launch count since the last reset; used by bench.py for the roofline line. */
+int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_launches,
+                      double* tree_ms, uint64_t* steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAKZERO_HIP_H */
