@@ -1,0 +1,90 @@
+"""ctypes binding of libtakzero_hip.so (include/takzero_hip.h).  There is no CPU fallback: if the
+HIP library is missing the import fails loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtakzero_hip.so")
+MAX_SQ = 36
+
+STATE_DTYPE = np.dtype([
+    ("colors", np.uint64, (MAX_SQ,)), ("height", np.uint8, (MAX_SQ,)), ("top", np.uint8, (MAX_SQ,)),
+    ("stones", np.uint8, (2,)), ("caps", np.uint8, (2,)), ("to_move", np.uint8), ("n", np.uint8),
+    ("half_komi", np.int8), ("pad0", np.uint8), ("ply", np.uint16), ("reversible_plies", np.uint16),
+], align=True)
+ROOT_INFO_DTYPE = np.dtype([
+    ("visit_count", np.uint32), ("n_children", np.uint32), ("eval_tag", np.uint8),
+    ("is_terminal_env", np.uint8), ("ply", np.uint16), ("eval_bits", np.uint32),
+    ("std_dev", np.float32), ("logit", np.float32), ("probability", np.float32)], align=True)
+assert STATE_DTYPE.itemsize == 376 and ROOT_INFO_DTYPE.itemsize == 28
+
+# every symbol include/takzero_hip.h declares
+SYMBOLS = [
+    "tz_last_error", "tz_version", "tz_device_count", "tz_state_from_tps", "tz_state_to_tps", "tz_move_to_ptn",
+    "tz_move_from_ptn", "tz_policy_size", "tz_input_channels", "tz_net_create", "tz_net_load_weights",
+    "tz_net_load_weights_mem", "tz_net_destroy", "tz_net_eval", "tz_net_encode", "tz_net_forward_raw",
+    "tz_search_create", "tz_search_destroy", "tz_search_set_positions", "tz_search_get_positions",
+    "tz_search_new_openings", "tz_search_simulate", "tz_search_apply_noise", "tz_search_root_info",
+    "tz_search_root_children", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
+    "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync",
+    "tz_search_profile",
+]
+
+_lib = None
+
+
+class TakzeroError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libtakzero_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `python -m takzero_amd.build` (hipcc, gfx950). "
+                          "takzero_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.tz_last_error.restype = C.c_char_p
+    lib.tz_state_from_tps.argtypes = [C.c_char_p, ci, ci, vp]
+    lib.tz_state_to_tps.argtypes = [vp, C.c_char_p, ci]
+    lib.tz_move_to_ptn.argtypes = [ci, C.c_uint16, C.c_char_p, ci]
+    lib.tz_move_from_ptn.argtypes = [ci, C.c_char_p, C.POINTER(C.c_uint16)]
+    lib.tz_net_create.argtypes = [ci, ci, ci, ci, ci, C.POINTER(vp)]
+    lib.tz_net_load_weights.argtypes = [vp, C.c_char_p]
+    lib.tz_net_load_weights_mem.argtypes = [vp, vp, C.c_size_t]
+    lib.tz_net_destroy.argtypes = [vp]
+    lib.tz_net_eval.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp]
+    lib.tz_net_encode.argtypes = [vp, ci, vp, vp]
+    lib.tz_net_forward_raw.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.tz_search_create.argtypes = [vp, ci, ci, ci, ci, ci, C.POINTER(vp)]
+    lib.tz_search_destroy.argtypes = [vp]
+    lib.tz_search_set_positions.argtypes = [vp, ci, vp, vp]
+    lib.tz_search_get_positions.argtypes = [vp, vp]
+    lib.tz_search_new_openings.argtypes = [vp, vp]
+    lib.tz_search_simulate.argtypes = [vp, vp, ci]
+    lib.tz_search_apply_noise.argtypes = [vp, vp, ci, cf]
+    lib.tz_search_root_info.argtypes = [vp, vp]
+    lib.tz_search_root_children.argtypes = [vp, ci] + [vp] * 7
+    lib.tz_search_select_best_actions.argtypes = [vp, vp]
+    lib.tz_search_improved_policy.argtypes = [vp, cf, ci, vp]
+    lib.tz_search_ube_target.argtypes = [vp, cf, vp]
+    lib.tz_search_step.argtypes = [vp, vp]
+    lib.tz_search_restart_terminal.argtypes = [vp, vp, vp]
+    lib.tz_search_gumbel_sh.argtypes = [vp, vp, ci, ci, vp, ci, vp]
+    lib.tz_search_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.tz_search_sync.argtypes = [vp]
+    lib.tz_search_profile.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_uint64)]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TakzeroError(rc, load().tz_last_error().decode(errors="replace"))

@@ -1,0 +1,303 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI:
+
+    Net          <- Network + Agent        takzero/src/network/mod.rs:10-45, search/agent.rs:5-14
+    BatchedMCTS  <- BatchedMCTS<B, E>      takzero/src/search/node/batched.rs:24-409
+
+Method names, argument meaning and error behaviour follow the reference; randomness is an
+argument wherever the reference takes `rng` (the draws stay with the caller).
+Everything here is plumbing: the work happens in libtakzero_hip.so on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ROOT_INFO_DTYPE, STATE_DTYPE, TakzeroError, check
+
+ARCH_NET4_SIMHASH, ARCH_NET5, ARCH_NET6_SIMHASH, ARCH_TEST = 4, 5, 6, 100
+PREC_BF16, PREC_F32 = 0, 1
+AGENT_NET, AGENT_DUMMY, AGENT_SIMPLE = 0, 1, 2
+EVAL_VALUE, EVAL_WIN, EVAL_LOSS, EVAL_DRAW = 0, 1, 2, 3
+TERMINAL_NONE, TERMINAL_WIN, TERMINAL_LOSS, TERMINAL_DRAW = -1, 0, 1, 2
+DISCOUNT_FACTOR = np.float32(0.997)  # search/mod.rs:7
+
+
+# ---------------------------------------------------------------- text helpers (takparse formats)
+def state_from_tps(tps, n, half_komi):
+    out = np.zeros(1, STATE_DTYPE)
+    check(_lib.load().tz_state_from_tps(tps.encode(), n, half_komi, out.ctypes.data))
+    return out[0]
+
+
+def state_to_tps(state):
+    arr = np.ascontiguousarray(np.asarray(state, dtype=STATE_DTYPE).reshape(1))
+    buf = C.create_string_buffer(512)
+    check(_lib.load().tz_state_to_tps(arr.ctypes.data, buf, 512))
+    return buf.value.decode()
+
+
+def move_to_ptn(n, move_index):
+    buf = C.create_string_buffer(32)
+    check(_lib.load().tz_move_to_ptn(n, int(move_index), buf, 32))
+    return buf.value.decode()
+
+
+def move_from_ptn(n, text):
+    out = C.c_uint16()
+    check(_lib.load().tz_move_from_ptn(n, text.encode(), C.byref(out)))
+    return out.value
+
+
+def policy_size(n):
+    return _lib.load().tz_policy_size(n)
+
+
+def input_channels(n):
+    return _lib.load().tz_input_channels(n)
+
+
+def eval_to_f32(tag, bits):
+    """impl From<Eval> for f32 (eval.rs:95-105)."""
+    if tag == EVAL_VALUE:
+        return np.uint32(bits).view(np.float32)
+    r, base, b = np.float32(1.0), DISCOUNT_FACTOR, int(bits)
+    while True:  # f32::powi (square and multiply)
+        if b & 1:
+            r = np.float32(r * base)
+        b >>= 1
+        if b == 0:
+            break
+        base = np.float32(base * base)
+    return np.float32(r * np.float32({EVAL_WIN: 1.0, EVAL_LOSS: -1.0, EVAL_DRAW: 0.0}[int(tag)]))
+
+
+def _states(states):
+    arr = np.ascontiguousarray(states, dtype=STATE_DTYPE)
+    return arr.reshape(-1)
+
+
+class Net:
+    """A network on one GPU.  `Net(arch=ARCH_NET5)` is Network::new; `load` is Network::load."""
+
+    def __init__(self, arch=ARCH_NET5, n=0, device=0, precision=PREC_BF16, blocks=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.tz_net_create(n, arch, device, precision, blocks, C.byref(h)))
+        self.h = h
+        self.arch, self.precision = arch, precision
+        self.n = {ARCH_NET5: 5, ARCH_NET4_SIMHASH: 4, ARCH_NET6_SIMHASH: 6}.get(arch, n)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tz_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, path):
+        check(self.lib.tz_net_load_weights(self.h, str(path).encode()))
+        return self
+
+    def load_tensors(self, tensors):
+        from .weights import dumps_tzw
+
+        blob = dumps_tzw(tensors)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        check(self.lib.tz_net_load_weights_mem(self.h, C.addressof(buf), len(blob)))
+        return self
+
+    def policy_value_uncertainty(self, env_batch, actions_batch):
+        """Agent::policy_value_uncertainty: returns (list of per-env logits arrays, values, variances)."""
+        st = _states(env_batch)
+        b = len(st)
+        if b == 0 or len(actions_batch) != b:
+            raise TakzeroError(-1, "env_batch and actions_batch must be non-empty and of equal length")
+        amax = max(1, max(len(a) for a in actions_batch))
+        idx = np.zeros((b, amax), np.uint16)
+        cnt = np.zeros(b, np.int32)
+        for i, a in enumerate(actions_batch):
+            cnt[i] = len(a)
+            idx[i, :len(a)] = a
+        logits = np.zeros((b, amax), np.float32)
+        value = np.zeros(b, np.float32)
+        var = np.zeros(b, np.float32)
+        check(self.lib.tz_net_eval(self.h, b, st.ctypes.data, idx.ctypes.data, cnt.ctypes.data, amax,
+                                   logits.ctypes.data, value.ctypes.data, var.ctypes.data))
+        return [logits[i, :cnt[i]].copy() for i in range(b)], value, var
+
+    def encode(self, env_batch):
+        st = _states(env_batch)
+        out = np.zeros((len(st), input_channels(self.n) * self.n * self.n), np.float32)
+        check(self.lib.tz_net_encode(self.h, len(st), st.ctypes.data, out.ctypes.data))
+        return out
+
+    def forward_raw(self, env_batch):
+        st = _states(env_batch)
+        b = len(st)
+        pol = np.zeros((b, policy_size(self.n)), np.float32)
+        val = np.zeros(b, np.float32)
+        ube = np.zeros(b, np.float32)
+        check(self.lib.tz_net_forward_raw(self.h, b, st.ctypes.data, pol.ctypes.data, val.ctypes.data, ube.ctypes.data))
+        return pol, val, ube
+
+
+class BatchedMCTS:
+    """BatchedMCTS<BATCH_SIZE, Game<N, HALF_KOMI>> on one GPU."""
+
+    def __init__(self, batch, n, half_komi, agent=None, agent_kind=None, node_capacity=0):
+        self.lib = _lib.load()
+        self.batch, self.n, self.half_komi = batch, n, half_komi
+        if agent_kind is None:
+            agent_kind = AGENT_NET if agent is not None else AGENT_DUMMY
+        self.agent = agent
+        h = C.c_void_p()
+        check(self.lib.tz_search_create(agent.h if agent is not None else None, agent_kind, batch, n, half_komi,
+                                        node_capacity, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tz_search_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- BatchedMCTS::new / from_envs / nodes_and_envs_mut
+    def new_openings(self, opening_choice):
+        c = np.ascontiguousarray(opening_choice, dtype=np.int32)
+        assert c.shape == (self.batch,)
+        check(self.lib.tz_search_new_openings(self.h, c.ctypes.data))
+
+    def set_positions(self, game_idx, states):
+        idx = np.ascontiguousarray(game_idx, dtype=np.int32)
+        st = _states(states)
+        assert len(idx) == len(st)
+        check(self.lib.tz_search_set_positions(self.h, len(idx), idx.ctypes.data, st.ctypes.data))
+
+    def get_positions(self):
+        out = np.zeros(self.batch, STATE_DTYPE)
+        check(self.lib.tz_search_get_positions(self.h, out.ctypes.data))
+        return out
+
+    # --- search
+    def simulate(self, betas, n_sims=1):
+        b = np.ascontiguousarray(betas, dtype=np.float32)
+        assert b.shape == (self.batch,)
+        check(self.lib.tz_search_simulate(self.h, b.ctypes.data, n_sims))
+
+    def apply_noise(self, noise, ratio):
+        nz = np.ascontiguousarray(noise, dtype=np.float32)
+        assert nz.ndim == 2 and nz.shape[0] == self.batch
+        check(self.lib.tz_search_apply_noise(self.h, nz.ctypes.data, nz.shape[1], ratio))
+
+    def gumbel_sequential_halving(self, betas, sampled_actions, search_budget, gumbel):
+        b = np.ascontiguousarray(betas, dtype=np.float32)
+        gm = np.ascontiguousarray(gumbel, dtype=np.float32)
+        out = np.zeros(self.batch, np.uint16)
+        check(self.lib.tz_search_gumbel_sh(self.h, b.ctypes.data, sampled_actions, search_budget, gm.ctypes.data,
+                                           gm.shape[1], out.ctypes.data))
+        return out
+
+    # --- results
+    def root_info(self):
+        out = np.zeros(self.batch, ROOT_INFO_DTYPE)
+        check(self.lib.tz_search_root_info(self.h, out.ctypes.data))
+        return out
+
+    def root_children(self, amax=None):
+        if amax is None:
+            amax = max(1, int(self.root_info()["n_children"].max()))
+        B = self.batch
+        out = dict(move_idx=np.zeros((B, amax), np.uint16), visits=np.zeros((B, amax), np.uint32),
+                   eval_tag=np.zeros((B, amax), np.uint8), eval_bits=np.zeros((B, amax), np.uint32),
+                   logit=np.zeros((B, amax), np.float32), prob=np.zeros((B, amax), np.float32),
+                   std_dev=np.zeros((B, amax), np.float32))
+        check(self.lib.tz_search_root_children(self.h, amax, *[out[k].ctypes.data for k in (
+            "move_idx", "visits", "eval_tag", "eval_bits", "logit", "prob", "std_dev")]))
+        return out
+
+    def select_best_actions(self):
+        out = np.zeros(self.batch, np.uint16)
+        check(self.lib.tz_search_select_best_actions(self.h, out.ctypes.data))
+        return out
+
+    def select_actions_in_selfplay(self, rng, weighted_random_steps, threshold=32, allowed_eval_drop=0.5):
+        """batched.rs:165-183 / node/mod.rs:170-207 with a numpy Generator in place of the Rust rng
+        (the draw itself is caller-side randomness; the candidate weights follow the reference)."""
+        best = self.select_best_actions()
+        info = self.root_info()
+        sample = (info["ply"] < weighted_random_steps) & (info["eval_tag"] == EVAL_VALUE) & (info["n_children"] > 0)
+        if not sample.any():
+            return best
+        ch = self.root_children()
+        out = best.copy()
+        for g in np.nonzero(sample)[0]:
+            nc = int(info["n_children"][g])
+            tags, bits, vis = ch["eval_tag"][g, :nc], ch["eval_bits"][g, :nc], ch["visits"][g, :nc]
+            keys = [_eval_key(t, b) for t, b in zip(tags, bits)]
+            bi = min(range(nc), key=lambda i: keys[i])
+            limit = keys[bi]
+            if tags[bi] == EVAL_VALUE:
+                limit = _eval_key(EVAL_VALUE, np.float32(np.uint32(bits[bi]).view(np.float32) + np.float32(allowed_eval_drop)).view(np.uint32))
+            w = np.array([0 if (vis[i] < threshold or tags[i] == EVAL_WIN or keys[i] > limit) else int(vis[i])
+                          for i in range(nc)], dtype=np.float64)
+            if w.sum() > 0:
+                out[g] = ch["move_idx"][g, rng.choice(nc, p=w / w.sum())]
+        return out
+
+    def improved_policy(self, visitations, amax=None):
+        if amax is None:
+            amax = max(1, int(self.root_info()["n_children"].max()))
+        out = np.zeros((self.batch, amax), np.float32)
+        check(self.lib.tz_search_improved_policy(self.h, visitations, amax, out.ctypes.data))
+        return out
+
+    def ube_target(self, beta):
+        out = np.zeros(self.batch, np.float32)
+        check(self.lib.tz_search_ube_target(self.h, beta, out.ctypes.data))
+        return out
+
+    # --- stepping
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.uint16)
+        assert a.shape == (self.batch,)
+        check(self.lib.tz_search_step(self.h, a.ctypes.data))
+
+    def restart_terminal_envs(self, opening_choice):
+        c = np.ascontiguousarray(opening_choice, dtype=np.int32)
+        out = np.zeros(self.batch, np.int8)
+        check(self.lib.tz_search_restart_terminal(self.h, c.ctypes.data, out.ctypes.data))
+        return out
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self.lib.tz_search_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def sync(self):
+        check(self.lib.tz_search_sync(self.h))
+
+    def profile(self, reset=0):
+        cm, cl, tm, st = C.c_double(), C.c_uint64(), C.c_double(), C.c_uint64()
+        check(self.lib.tz_search_profile(self.h, reset, C.byref(cm), C.byref(cl), C.byref(tm), C.byref(st)))
+        return dict(conv_ms=cm.value, conv_launches=cl.value, tree_ms=tm.value, steps=st.value)
+
+
+def _eval_key(tag, bits):
+    """Total order of Eval (eval.rs:138-163) as a sortable tuple."""
+    tag, bits = int(tag), int(bits)
+    if tag == EVAL_LOSS:
+        return (0, bits, 0.0)
+    if tag == EVAL_WIN:
+        return (2, -bits, 0.0)
+    if tag == EVAL_DRAW:
+        return (1, -0.05, -bits)  # draws sit at CONTEMPT; slower draw first
+    v = float(np.uint32(bits).view(np.float32))
+    return (1, v, float("inf")) if v != -0.05 else (1, v, float("inf"))

@@ -1,0 +1,61 @@
+"""Builds takzero_amd/libtakzero_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libtakzero_hip.so")
+ARCH = "gfx950"
+# (source, extra flags).  The tree kernels and the ABI glue do reference-order f32 arithmetic:
+# no FMA contraction there.  The network kernels keep the default (contraction on).
+UNITS = [
+    ("tz_text.cpp", ["-ffp-contract=off"]),
+    ("tz_tree.hip", ["-ffp-contract=off"]),
+    ("tz_capi.hip", ["-ffp-contract=off"]),
+    ("tz_nn.hip", []),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "takzero_hip.h"))
+    objs = []
+    procs = []
+    for src, extra in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("---- %s ----\n%s\n" % (src, out.decode(errors="replace")))
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or _stale(OUT, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", OUT] + objs
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

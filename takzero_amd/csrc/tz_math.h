@@ -15,7 +15,8 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define TZ_HD __host__ __device__ __forceinline__
 #else
 #define TZ_HD static inline

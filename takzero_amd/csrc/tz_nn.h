@@ -1,0 +1,48 @@
+// tz_nn.h — network object of libtakzero_hip.so (Network + Agent of the reference,
+// takzero/src/network/mod.rs:10-45, net5.rs:17-285, net6_simhash.rs:23-324).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "tz_engine.h"
+
+struct ConvW {
+    int taps = 0, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
+    uint16_t* w_mfma = nullptr;  // bf16 bits, fragment order [tap][kc][ct][lane][8]
+    float* w_f32 = nullptr;      // [tap][cout][cin]
+    float* bias = nullptr;       // [cout_pad]  (BatchNorm folded in)
+};
+
+struct tz_net {
+    int n = 0, nn = 0, arch = 0, device = 0, precision = 0, blocks = 0;
+    int cin = 0, cin_pad = 0, pol_ch = 0, pol_stride = 0, ppt = 0;
+    bool loaded = false, has_rnd = false, has_hash = false;
+    ConvW conv_in, policy;
+    std::vector<ConvW> res;  // 2 per block
+    float* heads = nullptr;  // [value conv w 256, ube conv w 256, value lin nn, ube lin nn, bv, bu, lbv, lbu]
+    ConvW rnd[2][3];         // [learning, target][input, hidden, final]
+    float rnd_min = 0.0f, rnd_max = 1.0f;
+    float* simhash = nullptr;    // [in_size][32] fp32, reference order (c*nn + px)
+    uint32_t* bitset = nullptr;  // 2^32 bits, allocated for hash archs
+    // work buffers, sized for max_batch positions
+    int max_batch = 0;
+    void *act_a = nullptr, *act_b = nullptr, *act_c = nullptr;  // [max_batch*nn][256] bf16 or f32
+    float* planes = nullptr;   // [max_batch][nn][cin] fp32 (f32 path, RND, hash, debug)
+    float* policy_out = nullptr;  // [max_batch*nn][pol_stride]
+    float *value = nullptr, *ube = nullptr, *variance = nullptr, *aux = nullptr;  // [max_batch]
+    void *rnd_in = nullptr, *rnd_h1 = nullptr, *rnd_h2 = nullptr;  // RND activations
+    float* rnd_out = nullptr;                                       // [2][max_batch][512]
+    hipStream_t stream = nullptr;
+    // profiling of the dominant kernel (residual-tower conv)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
+    bool profile = false;
+    double conv_ms = 0.0;
+    uint64_t conv_launches = 0;
+};
+
+int tz_net_ensure_batch(tz_net* net, int batch);
+// Evaluate `count` positions: slot i reads states_dev[game_index_dev ? game_index_dev[i] : i].
+// If count_dev is non-null the number of valid slots is read on the device (<= max_positions).
+int tz_net_forward_device(tz_net* net, const tz_state* states_dev, const int32_t* game_index_dev,
+                          const int32_t* count_dev, int count_host, int max_positions, hipStream_t st, NetOut* out);

@@ -1,0 +1,1124 @@
+// tz_nn.hip — policy / value / uncertainty network forward on gfx950.
+//
+// Replaces the LibTorch op sequence issued by the reference's Agent impls
+// (takzero/src/network/net5.rs:184-285, net6_simhash.rs:194-324, residual.rs:13-63, repr.rs:169-244;
+// SURVEY.md §2.2 rows a-j):
+//   * conv_mfma_kernel — 3x3 / 1x1 convolution and Linear as an im2col-free implicit GEMM on
+//     NHWC bf16 with v_mfma_f32_16x16x32_bf16: a workgroup owns P whole boards (P*N*N output
+//     pixels), stages their activations once in LDS and walks the 9 taps as row-shifted reads of
+//     that tile (out-of-board taps read a zero row); weights stream from L2 in MFMA-fragment order
+//     straight into registers; BatchNorm is folded into the weights, bias / residual / ReLU are
+//     fused into the epilogue; the first layer builds its input planes from the packed game
+//     state inside the tile loader (game_repr fused, repr.rs:169-228).
+//   * heads_kernel — value and UBE heads (1x1 conv + ReLU + Linear (+tanh)), one wave per board.
+//   * RND MLP (net5.rs:122-148,193-211) through the same MFMA kernel; SimHash lookup
+//     (net6_simhash.rs:208-256) with the 2^32-bit set resident in HBM.
+//   * an fp32 validation path (TZ_PREC_F32) with plain FMA kernels for the 1e-3 logit gate.
+#include "tz_nn.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDS_STRIDE = 528;  // bytes per LDS row: 256 bf16 + 16 B pad (bank spread for ds_read_b128)
+constexpr int FILTERS = 256;
+
+__host__ __device__ constexpr int ppt_for(int nb) { return nb == 1 ? 208 : nb == 3 ? 16 : nb == 4 ? 12 : nb == 5 ? 8 : 4; }
+
+__device__ __forceinline__ void default_reserves_d(int n, int& stones, int& caps) {
+    stones = n == 3 ? 10 : n == 4 ? 15 : n == 5 ? 21 : 30;
+    caps = n >= 5 ? 1 : 0;
+}
+
+// value of input plane `c` at square `px` of state s  (game_repr, repr.rs:169-228)
+template <int NB>
+__device__ __forceinline__ float plane_value(const tz_state* s, int px, int c, int flat_diff) {
+    constexpr int SS = 3 + (NB - 1) + (NB + 1), NN = NB * NB;
+    const int to_move = s->to_move;
+    if (c < 2 * SS) {
+        const int side = c / SS, k = c % SS;
+        const int top = s->top[px], h = s->height[px];
+        if (top == TZ_EMPTY) return 0.0f;
+        const unsigned long long colors = s->colors[px];
+        if (k < 3) {
+            const int topc = (int)((colors >> (h - 1)) & 1ull);
+            return (top == k + 1 && (topc != to_move) == (side == 1)) ? 1.0f : 0.0f;
+        }
+        const int idx = h - 2 - (k - 3);
+        if (idx < 0) return 0.0f;
+        const int color = (int)((colors >> idx) & 1ull);
+        return ((color != to_move) == (side == 1)) ? 1.0f : 0.0f;
+    }
+    const int e = c - 2 * SS;
+    int ds, dc;
+    default_reserves_d(NB, ds, dc);
+    const int mine = to_move, other = 1 - to_move;
+    switch (e) {
+        case 0: return (float)s->stones[mine] / (float)ds;
+        case 1: return dc ? (float)s->caps[mine] / (float)dc : 0.0f;
+        case 2: return (float)s->stones[other] / (float)ds;
+        case 3: return dc ? (float)s->caps[other] / (float)dc : 0.0f;
+        case 4: return to_move == 1 ? 1.0f : 0.0f;
+        case 5: return ((float)flat_diff - (float)s->half_komi / 2.0f) / (float)NN;
+        default: return 0.0f;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ int state_flat_diff(const tz_state* s) {
+    int d = 0;
+    for (int i = 0; i < NB * NB; i++) {
+        if (s->top[i] == TZ_FLAT) {
+            const int col = (int)((s->colors[i] >> (s->height[i] - 1)) & 1ull);
+            d += col == 0 ? 1 : -1;
+        }
+    }
+    return d;
+}
+
+struct ConvArgs {
+    const void* in;
+    const tz_state* states;
+    const int32_t* game_index;
+    const int32_t* count_dev;
+    int count_host;
+    const uint16_t* w;
+    const float* bias;
+    const void* residual;
+    void* out;
+    int cin_pad, kc_total, ct_total, out_stride, cin_real;
+    int relu, out_f32, has_res;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on MFMA.  Tile = P boards x (128*RN) output channels per workgroup,
+// 8 waves split the output channels (16*RN each) so each wave's weight fragments are private and
+// come straight from global memory; the activation tile is shared through LDS.
+template <int NB, int P, int RN, int TAPS, bool FROM_STATE>
+__global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 1, ZROW = RT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int count = a.count_dev ? *a.count_dev : a.count_host;
+    const int pos0 = blockIdx.x * P;
+    if (pos0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, lr = lane & 15;
+    const int valid_rows = min(ROWS, (count - pos0) * NN);
+    const size_t m0 = (size_t)pos0 * NN;
+
+    int yx[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int r = rt * 16 + lr;
+        const int px = r % NN;
+        yx[rt] = r < ROWS ? ((px / NB) | ((px % NB) << 8)) : 0x7f7f;
+    }
+    f32x4 acc[RT][RN];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int j = 0; j < RN; j++) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ct0 = (blockIdx.y * 8 + wave) * RN;
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(a.w) + lane;
+    auto wptr = [&](int tap, int kcg, int j) -> const bf16x8* {
+        return wfrag + ((size_t)(tap * a.kc_total + kcg) * a.ct_total + (ct0 + j)) * 64;
+    };
+
+    const int nslices = (a.cin_pad + 255) / 256;
+    for (int slice = 0; slice < nslices; slice++) {
+        const int cs = min(256, a.cin_pad - slice * 256);
+        const int kcs = cs / 32, cpr = cs / 8;
+        __syncthreads();
+        if constexpr (FROM_STATE) {
+            // game_repr fused into the tile loader: one thread per (board, square)
+            if (tid < LROWS) {
+                const int row = tid;
+                const bool ok = row < valid_rows;
+                const tz_state* s = nullptr;
+                int px = 0, fd = 0;
+                if (ok) {
+                    const int pos = pos0 + row / NN;
+                    px = row % NN;
+                    s = a.states + (a.game_index ? a.game_index[pos] : pos);
+                    fd = state_flat_diff<NB>(s);
+                }
+                for (int c8 = 0; c8 < cpr; c8++) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int c = c8 * 8 + k;
+                        v[k] = (__bf16)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
+                    }
+                    *reinterpret_cast<bf16x8*>(lds + row * LDS_STRIDE + c8 * 16) = v;
+                }
+            }
+        } else {
+            const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+            for (int id = tid; id < LROWS * cpr; id += 512) {
+                const int row = id / cpr, ci = id % cpr;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < valid_rows)
+                    v = *reinterpret_cast<const uint4*>(in + (m0 + row) * a.cin_pad + slice * 256 + ci * 8);
+                *reinterpret_cast<uint4*>(lds + row * LDS_STRIDE + ci * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        bf16x8 bnext[RN];
+#pragma unroll
+        for (int j = 0; j < RN; j++) bnext[j] = *wptr(0, slice * 8, j);
+        for (int tap = 0; tap < TAPS; tap++) {
+            const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
+            int abase[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int y = (yx[rt] & 0xff) + dy, x = (yx[rt] >> 8) + dx;
+                const bool ok = y >= 0 && y < NB && x >= 0 && x < NB;
+                const int sr = ok ? rt * 16 + lr + dy * NB + dx : ZROW;
+                abase[rt] = sr * LDS_STRIDE + q * 16;
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; kc++) {
+                if (kc < kcs) {
+                    bf16x8 bcur[RN];
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bcur[j] = bnext[j];
+                    if (kc + 1 < kcs) {
+#pragma unroll
+                        for (int j = 0; j < RN; j++) bnext[j] = *wptr(tap, slice * 8 + kc + 1, j);
+                    } else if (tap + 1 < TAPS) {
+#pragma unroll
+                        for (int j = 0; j < RN; j++) bnext[j] = *wptr(tap + 1, slice * 8, j);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + kc * 64);
+#pragma unroll
+                        for (int j = 0; j < RN; j++)
+                            acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], av, acc[rt][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: D[row = channel (q*4 + reg), col = pixel (lr)]
+#pragma unroll
+    for (int j = 0; j < RN; j++) {
+        const int cbase = (ct0 + j) * 16 + q * 4;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + cbase);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int r = rt * 16 + lr;
+            if (r >= valid_rows) continue;
+            f32x4 v = acc[rt][j] + bias;
+            const size_t o = (m0 + r) * a.out_stride + cbase;
+            if (a.has_res) {
+                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const uint16_t*>(a.residual) + o);
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] += (float)rv[k];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            }
+            if (a.out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = v;
+            } else {
+                bf16x4 ov;
+#pragma unroll
+                for (int k = 0; k < 4; k++) ov[k] = (__bf16)v[k];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(a.out) + o) = ov;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 validation path: one thread per (row, output channel); weights [tap][cin][cout].
+template <int NB>
+__global__ void conv_f32_kernel(const float* in, const float* w, const float* bias, const float* residual, float* out,
+                                const int32_t* count_dev, int count_host, int taps, int cin, int in_stride, int cout,
+                                int out_stride, int relu) {
+    constexpr int NN = NB * NB;
+    const int count = count_dev ? *count_dev : count_host;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rows = (size_t)count * NN;
+    if (idx >= rows * cout) return;
+    const size_t row = idx / cout;
+    const int co = (int)(idx % cout);
+    const int px = (int)(row % NN), y = px / NB, x = px % NB;
+    float acc = 0.0f;
+    for (int t = 0; t < taps; t++) {
+        const int dy = taps == 9 ? t / 3 - 1 : 0, dx = taps == 9 ? t % 3 - 1 : 0;
+        if (y + dy < 0 || y + dy >= NB || x + dx < 0 || x + dx >= NB) continue;
+        const float* ip = in + (row + dy * NB + dx) * in_stride;
+        const float* wp = w + (size_t)t * cin * cout + co;
+        for (int c = 0; c < cin; c++) acc = fmaf(ip[c], wp[(size_t)c * cout], acc);
+    }
+    acc += bias[co];
+    if (residual) acc += residual[row * out_stride + co];
+    if (relu) acc = acc > 0.f ? acc : 0.f;
+    out[row * out_stride + co] = acc;
+}
+
+// input planes NHWC fp32: planes[slot][px][cin]
+template <int NB>
+__global__ void encode_kernel(const tz_state* states, const int32_t* game_index, const int32_t* count_dev,
+                              int count_host, int cin, float* planes) {
+    constexpr int NN = NB * NB;
+    const int count = count_dev ? *count_dev : count_host;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * NN) return;
+    const int pos = idx / NN, px = idx % NN;
+    const tz_state* s = states + (game_index ? game_index[pos] : pos);
+    const int fd = state_flat_diff<NB>(s);
+    for (int c = 0; c < cin; c++) planes[(size_t)idx * cin + c] = plane_value<NB>(s, px, c, fd);
+}
+
+// value + UBE heads: conv1x1(256->1)+bias, ReLU, Linear(nn->1) (+tanh for value). One wave per board.
+template <typename T>
+__global__ __launch_bounds__(64) void heads_kernel(const T* act, const float* hw, const int32_t* count_dev,
+                                                   int count_host, int nn, float* value, float* ube) {
+    const int count = count_dev ? *count_dev : count_host;
+    const int pos = blockIdx.x, l = threadIdx.x;
+    if (pos >= count) return;
+    float wv[4], wu[4];
+    for (int k = 0; k < 4; k++) {
+        wv[k] = hw[l * 4 + k];
+        wu[k] = hw[FILTERS + l * 4 + k];
+    }
+    const float* lv = hw + 2 * FILTERS;
+    const float* lu = lv + nn;
+    const float bv = lu[nn], bu = lu[nn + 1], lbv = lu[nn + 2], lbu = lu[nn + 3];
+    float sv = 0.f, su = 0.f;
+    for (int px = 0; px < nn; px++) {
+        const T* p = act + ((size_t)pos * nn + px) * FILTERS + l * 4;
+        float dv = 0.f, du = 0.f;
+        for (int k = 0; k < 4; k++) {
+            const float x = (float)p[k];
+            dv += x * wv[k];
+            du += x * wu[k];
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            dv += __shfl_xor(dv, d);
+            du += __shfl_xor(du, d);
+        }
+        dv += bv;
+        du += bu;
+        sv += (dv > 0.f ? dv : 0.f) * lv[px];
+        su += (du > 0.f ? du : 0.f) * lu[px];
+    }
+    if (l == 0) {
+        value[pos] = tanhf(sv + lbv);
+        ube[pos] = su + lbu;
+    }
+}
+
+// RND input: x / sum(x^2) (net5.rs:127), written in NHWC plane order (weights are permuted to match)
+template <typename T>
+__global__ __launch_bounds__(64) void rnd_prep_kernel(const float* planes, const int32_t* count_dev, int count_host,
+                                                      int in_size, int out_stride, T* out) {
+    const int count = count_dev ? *count_dev : count_host;
+    const int pos = blockIdx.x, l = threadIdx.x;
+    if (pos >= count) return;
+    const float* x = planes + (size_t)pos * in_size;
+    float ss = 0.f;
+    for (int i = l; i < in_size; i += 64) ss += x[i] * x[i];
+    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+    for (int i = l; i < out_stride; i += 64) out[(size_t)pos * out_stride + i] = (T)(i < in_size ? x[i] / ss : 0.f);
+}
+
+// variance = clamp(max(exp(ube), local), 0, 4)  (net5.rs:271-278, net6_simhash.rs:311-318)
+__global__ __launch_bounds__(64) void rnd_finish_kernel(const float* learn, const float* target, const float* ube,
+                                                        const int32_t* count_dev, int count_host, int dim, float rmin,
+                                                        float rmax, float* variance) {
+    const int count = count_dev ? *count_dev : count_host;
+    const int pos = blockIdx.x, l = threadIdx.x;
+    if (pos >= count) return;
+    float s = 0.f;
+    for (int i = l; i < dim; i += 64) {
+        const float d = learn[(size_t)pos * dim + i] - target[(size_t)pos * dim + i];
+        s += d * d;
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (l == 0) {
+        float norm = (s - rmin) / (rmax - rmin);
+        norm = fminf(fmaxf(norm, 0.f), 1.f) * 4.0f;
+        variance[pos] = fminf(fmaxf(fmaxf(expf(ube[pos]), norm), 0.f), 4.f);
+    }
+}
+
+__global__ void plain_variance_kernel(const float* ube, const float* local, const int32_t* count_dev, int count_host,
+                                      float* variance) {
+    const int count = count_dev ? *count_dev : count_host;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= count) return;
+    const float loc = local ? local[pos] : 0.f;
+    variance[pos] = fminf(fmaxf(fmaxf(expf(ube[pos]), loc), 0.f), 4.f);
+}
+
+// SimHash (net6_simhash.rs:208-256): sign bits of planes (to-move plane zeroed) x matrix[in][32]
+__global__ __launch_bounds__(64) void simhash_kernel(const float* planes, const float* matrix, const uint32_t* bitset,
+                                                     const int32_t* count_dev, int count_host, int nn, int cin,
+                                                     float* local, uint32_t* index_out) {
+    const int count = count_dev ? *count_dev : count_host;
+    const int pos = blockIdx.x, l = threadIdx.x;
+    if (pos >= count) return;
+    const int bit = l & 31, half = l >> 5;
+    const int in_size = nn * cin, skip = cin - 2;
+    float s = 0.f;
+    for (int k = half; k < in_size; k += 2) {  // k = c*nn + px (reference flattening)
+        const int c = k / nn, px = k % nn;
+        if (c == skip) continue;
+        s += planes[((size_t)pos * nn + px) * cin + c] * matrix[(size_t)k * 32 + bit];
+    }
+    s += __shfl_xor(s, 32);
+    const unsigned long long m = __ballot(!(s < 0.0f) && l < 32);
+    const uint32_t index = (uint32_t)m;
+    if (l == 0) {
+        const bool seen = bitset && ((bitset[index >> 5] >> (index & 31)) & 1u);
+        local[pos] = seen ? 0.0f : 4.0f;
+        if (index_out) index_out[pos] = index;
+    }
+}
+
+// logits of the legal actions: out[b][j] = policy[b][px(a)][ch(a)]  (net5.rs:239-267)
+__global__ void gather_kernel(const float* policy, int nn, int stride, const uint16_t* legal, const int32_t* cnt,
+                              int amax, int batch, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * amax) return;
+    const int b = idx / amax, j = idx % amax;
+    float v = 0.f;
+    if (j < cnt[b]) {
+        const int a = legal[idx];
+        v = policy[((size_t)b * nn + a % nn) * stride + a / nn];
+    }
+    out[idx] = v;
+}
+// policy tensor in the reference's NCHW flattening (net5.rs:238): out[b][ch*nn + px]
+__global__ void policy_nchw_kernel(const float* policy, int nn, int stride, int channels, int batch, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * channels * nn) return;
+    const int b = idx / (channels * nn), r = idx % (channels * nn);
+    const int ch = r / nn, px = r % nn;
+    out[idx] = policy[((size_t)b * nn + px) * stride + ch];
+}
+__global__ void planes_nchw_kernel(const float* planes, int nn, int cin, int batch, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * cin * nn) return;
+    const int b = idx / (cin * nn), r = idx % (cin * nn);
+    const int c = r / nn, px = r % nn;
+    out[idx] = planes[((size_t)b * nn + px) * cin + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+uint16_t f2bf(float f) {  // round to nearest even; NaN stays NaN
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct Tensor {
+    std::vector<uint32_t> dims;
+    const float* data;
+    size_t size;
+};
+typedef std::map<std::string, Tensor> TensorMap;
+
+int parse_tzw(const unsigned char* p, size_t bytes, TensorMap& out) {
+    if (bytes < 8 || memcmp(p, "TZW1", 4)) return tz_fail(TZ_EPARSE, "weights: bad magic");
+    uint32_t count;
+    memcpy(&count, p + 4, 4);
+    size_t off = 8;
+    for (uint32_t i = 0; i < count; i++) {
+        if (off + 2 > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        uint16_t ln;
+        memcpy(&ln, p + off, 2);
+        off += 2;
+        if (off + ln + 1 > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        std::string name((const char*)p + off, ln);
+        off += ln;
+        const int nd = p[off++];
+        Tensor t;
+        t.size = 1;
+        if (off + 4 * (size_t)nd > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        for (int d = 0; d < nd; d++) {
+            uint32_t v;
+            memcpy(&v, p + off, 4);
+            off += 4;
+            t.dims.push_back(v);
+            t.size *= v;
+        }
+        if (off + 4 * t.size > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        t.data = reinterpret_cast<const float*>(p + off);  // may be unaligned: copied with memcpy below
+        off += 4 * t.size;
+        out[name] = t;
+    }
+    return TZ_OK;
+}
+
+int get_tensor(const TensorMap& m, const std::string& name, size_t expect, std::vector<float>& out) {
+    auto it = m.find(name);
+    if (it == m.end()) return tz_fail(TZ_EPARSE, "weights: missing tensor " + name);
+    if (it->second.size != expect)
+        return tz_fail(TZ_EPARSE, "weights: tensor " + name + " has " + std::to_string(it->second.size) + " elements, expected " +
+                                      std::to_string(expect));
+    out.resize(expect);
+    memcpy(out.data(), it->second.data, 4 * expect);
+    return TZ_OK;
+}
+
+template <typename T>
+int upload(const std::vector<T>& h, T** dev) {
+    T* d = nullptr;
+    TZ_HIP(hipMalloc(&d, h.size() * sizeof(T)));
+    TZ_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = d;
+    return TZ_OK;
+}
+
+// Build device weights of one conv / linear layer from w[cout][cin][taps] (+ optional BN fold).
+// in_perm (optional): source input index for each of my input indices.
+int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const std::vector<float>& w,
+                const std::vector<float>& scale, const std::vector<float>& bias, const std::vector<int>* in_perm,
+                ConvW* L) {
+    L->taps = taps;
+    L->cin = cin;
+    L->cin_pad = (cin + 31) / 32 * 32;
+    L->cout = cout;
+    L->cout_pad = (cout + cout_mult - 1) / cout_mult * cout_mult;
+    auto W = [&](int co, int ci, int t) -> float {
+        const int src = in_perm ? (*in_perm)[ci] : ci;
+        return w[((size_t)co * cin + src) * taps + t] * (scale.empty() ? 1.0f : scale[co]);
+    };
+    std::vector<float> b(L->cout_pad, 0.0f);
+    for (int co = 0; co < cout; co++) b[co] = bias.empty() ? 0.0f : bias[co];
+    int rc = upload(b, &L->bias);
+    if (rc) return rc;
+    if (precision == TZ_PREC_BF16) {
+        const int kc_total = L->cin_pad / 32, ct_total = L->cout_pad / 16;
+        std::vector<uint16_t> p((size_t)taps * kc_total * ct_total * 64 * 8, 0);
+        for (int t = 0; t < taps; t++)
+            for (int kc = 0; kc < kc_total; kc++)
+                for (int ct = 0; ct < ct_total; ct++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int co = ct * 16 + (lane & 15);
+                        if (co >= cout) continue;
+                        for (int j = 0; j < 8; j++) {
+                            const int ci = kc * 32 + 8 * (lane >> 4) + j;
+                            if (ci >= cin) continue;
+                            p[((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j] = f2bf(W(co, ci, t));
+                        }
+                    }
+        return upload(p, &L->w_mfma);
+    }
+    std::vector<float> f((size_t)taps * cin * cout);
+    for (int t = 0; t < taps; t++)
+        for (int ci = 0; ci < cin; ci++)
+            for (int co = 0; co < cout; co++) f[((size_t)t * cin + ci) * cout + co] = W(co, ci, t);
+    return upload(f, &L->w_f32);
+}
+
+void free_layer(ConvW* L) {
+    if (L->w_mfma) (void)hipFree(L->w_mfma);
+    if (L->w_f32) (void)hipFree(L->w_f32);
+    if (L->bias) (void)hipFree(L->bias);
+    *L = ConvW();
+}
+
+int bn_fold(const TensorMap& m, const std::string& p, int c, std::vector<float>& scale, std::vector<float>& bias) {
+    std::vector<float> g, b, mean, var;
+    int rc;
+    if ((rc = get_tensor(m, p + ".weight", c, g))) return rc;
+    if ((rc = get_tensor(m, p + ".bias", c, b))) return rc;
+    if ((rc = get_tensor(m, p + ".running_mean", c, mean))) return rc;
+    if ((rc = get_tensor(m, p + ".running_var", c, var))) return rc;
+    scale.resize(c);
+    bias.resize(c);
+    for (int i = 0; i < c; i++) {
+        const float s = g[i] / sqrtf(var[i] + 1e-5f);  // tch BatchNormConfig::default eps
+        scale[i] = s;
+        bias[i] = b[i] - mean[i] * s;
+    }
+    return TZ_OK;
+}
+
+struct NetWeights {  // everything tz_net_load_weights replaces, so a failed load changes nothing
+    ConvW conv_in, policy;
+    std::vector<ConvW> res;
+    float* heads = nullptr;
+    ConvW rnd[2][3];
+    float rnd_min = 0.f, rnd_max = 1.f;
+    float* simhash = nullptr;
+};
+
+void free_weights(NetWeights& w) {
+    free_layer(&w.conv_in);
+    free_layer(&w.policy);
+    for (auto& l : w.res) free_layer(&l);
+    w.res.clear();
+    if (w.heads) (void)hipFree(w.heads);
+    w.heads = nullptr;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 3; b++) free_layer(&w.rnd[a][b]);
+    if (w.simhash) (void)hipFree(w.simhash);
+    w.simhash = nullptr;
+}
+
+int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
+    const int nn = net->nn, cin = net->cin, prec = net->precision;
+    std::vector<float> w, scale, bias;
+    int rc;
+    if ((rc = get_tensor(m, "core.input_conv2d.weight", (size_t)FILTERS * cin * 9, w))) return rc;
+    if ((rc = bn_fold(m, "core.batch_norm", FILTERS, scale, bias))) return rc;
+    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in))) return rc;
+    W.res.resize(2 * net->blocks);
+    for (int b = 0; b < net->blocks; b++)
+        for (int h = 0; h < 2; h++) {
+            const std::string p = "core.res_block_" + std::to_string(b) + (h ? ".b" : ".a");
+            if ((rc = get_tensor(m, p + ".conv2d.weight", (size_t)FILTERS * FILTERS * 9, w))) return rc;
+            if ((rc = bn_fold(m, p + ".batch_norm", FILTERS, scale, bias))) return rc;
+            if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h]))) return rc;
+        }
+    if ((rc = get_tensor(m, "policy.conv2d.weight", (size_t)net->pol_ch * FILTERS * 9, w))) return rc;
+    if ((rc = get_tensor(m, "policy.conv2d.bias", net->pol_ch, bias))) return rc;
+    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy))) return rc;
+    // heads
+    std::vector<float> hv, hu, lv, lu, t1;
+    if ((rc = get_tensor(m, "value.conv2d.weight", FILTERS, hv))) return rc;
+    if ((rc = get_tensor(m, "ube.conv2d.weight", FILTERS, hu))) return rc;
+    if ((rc = get_tensor(m, "value.linear.weight", nn, lv))) return rc;
+    if ((rc = get_tensor(m, "ube.linear.weight", nn, lu))) return rc;
+    std::vector<float> hw;
+    hw.insert(hw.end(), hv.begin(), hv.end());
+    hw.insert(hw.end(), hu.begin(), hu.end());
+    hw.insert(hw.end(), lv.begin(), lv.end());
+    hw.insert(hw.end(), lu.begin(), lu.end());
+    for (const char* nm : {"value.conv2d.bias", "ube.conv2d.bias", "value.linear.bias", "ube.linear.bias"}) {
+        if ((rc = get_tensor(m, nm, 1, t1))) return rc;
+        hw.push_back(t1[0]);
+    }
+    if ((rc = upload(hw, &W.heads))) return rc;
+    if (net->has_rnd) {
+        const int in_size = cin * nn;
+        std::vector<int> perm(in_size);  // my index px*cin + c  <-  reference index c*nn + px
+        for (int px = 0; px < nn; px++)
+            for (int c = 0; c < cin; c++) perm[px * cin + c] = c * nn + px;
+        const char* nets[2] = {"rnd_learning", "rnd_target"};
+        const char* layers[3] = {"input_linear", "hidden_linear", "final_linear"};
+        const int dims[4] = {in_size, 1024, 1024, 512};
+        for (int a = 0; a < 2; a++)
+            for (int l = 0; l < 3; l++) {
+                const std::string p = std::string(nets[a]) + "." + layers[l];
+                if ((rc = get_tensor(m, p + ".weight", (size_t)dims[l + 1] * dims[l], w))) return rc;
+                if ((rc = get_tensor(m, p + ".bias", dims[l + 1], bias))) return rc;
+                if ((rc = build_layer(prec, 1, dims[l], dims[l + 1], 256, w, {}, bias, l == 0 ? &perm : nullptr, &W.rnd[a][l])))
+                    return rc;
+            }
+        if ((rc = get_tensor(m, "min", 1, t1))) return rc;
+        W.rnd_min = t1[0];
+        if ((rc = get_tensor(m, "max", 1, t1))) return rc;
+        W.rnd_max = t1[0];
+    }
+    if (net->has_hash) {
+        if ((rc = get_tensor(m, "simhash_matrix", (size_t)cin * nn * 32, w))) return rc;
+        if ((rc = upload(w, &W.simhash))) return rc;
+    }
+    return TZ_OK;
+}
+
+template <int NB, int RN, int TAPS, bool FROM_STATE>
+int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_t st) {
+    constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 1;
+    const size_t smem = (size_t)LROWS * LDS_STRIDE;
+    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((max_positions + P - 1) / P, n_blocks_y);
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("conv launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+// one bf16 layer.  in==nullptr -> first layer from packed states.
+int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* states, const int32_t* gidx,
+              const int32_t* count_dev, int count_host, int max_positions, const void* residual, void* out,
+              int out_stride, bool relu, bool out_f32, bool board, hipStream_t st) {
+    ConvArgs a;
+    a.in = in;
+    a.states = states;
+    a.game_index = gidx;
+    a.count_dev = count_dev;
+    a.count_host = count_host;
+    a.w = L.w_mfma;
+    a.bias = L.bias;
+    a.residual = residual;
+    a.out = out;
+    a.cin_pad = L.cin_pad;
+    a.kc_total = L.cin_pad / 32;
+    a.ct_total = L.cout_pad / 16;
+    a.out_stride = out_stride;
+    a.cin_real = L.cin;
+    a.relu = relu;
+    a.out_f32 = out_f32;
+    a.has_res = residual != nullptr;
+    const bool from_state = in == nullptr;
+    if (!board) return launch_conv<1, 2, 1, false>(a, max_positions, L.cout_pad / 256, st);
+    const bool rn2 = L.cout_pad % 256 == 0;
+    const int by = rn2 ? L.cout_pad / 256 : L.cout_pad / 128;
+#define TZ_CONV_CASE(NBV)                                                                   \
+    case NBV:                                                                               \
+        if (from_state) return launch_conv<NBV, 2, 9, true>(a, max_positions, by, st);      \
+        if (rn2) return launch_conv<NBV, 2, 9, false>(a, max_positions, by, st);            \
+        return launch_conv<NBV, 1, 9, false>(a, max_positions, by, st);
+    switch (net->n) {
+        TZ_CONV_CASE(3)
+        TZ_CONV_CASE(4)
+        TZ_CONV_CASE(5)
+        TZ_CONV_CASE(6)
+    }
+#undef TZ_CONV_CASE
+    return tz_fail(TZ_EINVAL, "conv: unsupported board size");
+}
+
+int conv_f32(tz_net* net, const ConvW& L, const float* in, int in_stride, const int32_t* count_dev, int count_host,
+             int max_positions, const float* residual, float* out, int out_stride, bool relu, bool board,
+             hipStream_t st) {
+    const int nn = board ? net->nn : 1;
+    const size_t total = (size_t)max_positions * nn * L.cout;
+    const int blocks = (int)((total + 255) / 256);
+#define TZ_F32_CASE(NBV)                                                                                       \
+    case NBV:                                                                                                  \
+        conv_f32_kernel<NBV><<<blocks, 256, 0, st>>>(in, L.w_f32, L.bias, residual, out, count_dev, count_host, \
+                                                     L.taps, L.cin, in_stride, L.cout, out_stride, relu ? 1 : 0); \
+        break;
+    switch (board ? net->n : 1) {
+        TZ_F32_CASE(1)
+        TZ_F32_CASE(3)
+        TZ_F32_CASE(4)
+        TZ_F32_CASE(5)
+        TZ_F32_CASE(6)
+        default: return tz_fail(TZ_EINVAL, "conv_f32: unsupported board size");
+    }
+#undef TZ_F32_CASE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("conv_f32 launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+int encode(tz_net* net, const tz_state* states, const int32_t* gidx, const int32_t* count_dev, int count_host,
+           int max_positions, hipStream_t st) {
+    const int total = max_positions * net->nn, blocks = (total + 127) / 128;
+    switch (net->n) {
+        case 3: encode_kernel<3><<<blocks, 128, 0, st>>>(states, gidx, count_dev, count_host, net->cin, net->planes); break;
+        case 4: encode_kernel<4><<<blocks, 128, 0, st>>>(states, gidx, count_dev, count_host, net->cin, net->planes); break;
+        case 5: encode_kernel<5><<<blocks, 128, 0, st>>>(states, gidx, count_dev, count_host, net->cin, net->planes); break;
+        case 6: encode_kernel<6><<<blocks, 128, 0, st>>>(states, gidx, count_dev, count_host, net->cin, net->planes); break;
+        default: return tz_fail(TZ_EINVAL, "encode: unsupported board size");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("encode launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+int tz_net_ensure_batch(tz_net* net, int batch) {
+    if (batch <= net->max_batch) return TZ_OK;
+    TZ_HIP(hipSetDevice(net->device));
+    TZ_HIP(hipStreamSynchronize(net->stream));
+    void** bufs[] = {&net->act_a, &net->act_b, &net->act_c, (void**)&net->planes, (void**)&net->policy_out,
+                     (void**)&net->value, (void**)&net->ube, (void**)&net->variance, (void**)&net->aux,
+                     &net->rnd_in, &net->rnd_h1, &net->rnd_h2, (void**)&net->rnd_out};
+    for (auto b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    const size_t esz = net->precision == TZ_PREC_BF16 ? 2 : 4;
+    const size_t rows = (size_t)batch * net->nn;
+    TZ_HIP(hipMalloc(&net->act_a, rows * FILTERS * esz));
+    TZ_HIP(hipMalloc(&net->act_b, rows * FILTERS * esz));
+    TZ_HIP(hipMalloc(&net->act_c, rows * FILTERS * esz));
+    TZ_HIP(hipMalloc(&net->planes, rows * net->cin * sizeof(float)));
+    TZ_HIP(hipMalloc(&net->policy_out, rows * net->pol_stride * sizeof(float)));
+    TZ_HIP(hipMalloc(&net->value, batch * sizeof(float)));
+    TZ_HIP(hipMalloc(&net->ube, batch * sizeof(float)));
+    TZ_HIP(hipMalloc(&net->variance, batch * sizeof(float)));
+    TZ_HIP(hipMalloc(&net->aux, batch * sizeof(float)));
+    if (net->has_rnd) {
+        const size_t in_pad = (size_t)(net->cin * net->nn + 31) / 32 * 32;
+        TZ_HIP(hipMalloc(&net->rnd_in, (size_t)batch * in_pad * esz));
+        TZ_HIP(hipMalloc(&net->rnd_h1, (size_t)batch * 1024 * esz));
+        TZ_HIP(hipMalloc(&net->rnd_h2, (size_t)batch * 1024 * esz));
+        TZ_HIP(hipMalloc(&net->rnd_out, (size_t)2 * batch * 512 * sizeof(float)));
+    }
+    net->max_batch = batch;
+    return TZ_OK;
+}
+
+int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gidx, const int32_t* count_dev,
+                          int count_host, int max_positions, hipStream_t st, NetOut* out) {
+    if (!net->loaded) return tz_fail(TZ_ESTATE, "network has no weights loaded");
+    if (max_positions > net->max_batch) return tz_fail(TZ_EINVAL, "forward: batch exceeds the network's buffers");
+    int rc;
+    const bool bf = net->precision == TZ_PREC_BF16;
+    const int nn = net->nn;
+    const bool need_planes = !bf || net->has_rnd || net->has_hash;
+    if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
+    void *x = net->act_a, *t = net->act_b, *y = net->act_c;
+    if (bf) {
+        if ((rc = conv_bf16(net, net->conv_in, nullptr, states, gidx, count_dev, count_host, max_positions, nullptr, x, FILTERS,
+                            true, false, true, st)))
+            return rc;
+        for (int b = 0; b < net->blocks; b++) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (net->profile) {
+                TZ_HIP(hipEventCreate(&e0));
+                TZ_HIP(hipEventCreate(&e1));
+                TZ_HIP(hipEventRecord(e0, st));
+            }
+            if ((rc = conv_bf16(net, net->res[2 * b], x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr, t,
+                                FILTERS, true, false, true, st)))
+                return rc;
+            if ((rc = conv_bf16(net, net->res[2 * b + 1], t, nullptr, nullptr, count_dev, count_host, max_positions, x, y,
+                                FILTERS, true, false, true, st)))
+                return rc;
+            if (net->profile) {
+                TZ_HIP(hipEventRecord(e1, st));
+                net->conv_events.push_back({e0, e1});
+                net->conv_launches += 2;
+            }
+            std::swap(x, y);
+        }
+        if ((rc = conv_bf16(net, net->policy, x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
+                            net->policy_out, net->pol_stride, false, true, true, st)))
+            return rc;
+        heads_kernel<__bf16><<<max_positions, 64, 0, st>>>((const __bf16*)x, net->heads, count_dev, count_host, nn, net->value, net->ube);
+    } else {
+        float *fx = (float*)x, *ft = (float*)t, *fy = (float*)y;
+        if ((rc = conv_f32(net, net->conv_in, net->planes, net->cin, count_dev, count_host, max_positions, nullptr, fx, FILTERS,
+                           true, true, st)))
+            return rc;
+        for (int b = 0; b < net->blocks; b++) {
+            if ((rc = conv_f32(net, net->res[2 * b], fx, FILTERS, count_dev, count_host, max_positions, nullptr, ft, FILTERS, true,
+                               true, st)))
+                return rc;
+            if ((rc = conv_f32(net, net->res[2 * b + 1], ft, FILTERS, count_dev, count_host, max_positions, fx, fy, FILTERS, true,
+                               true, st)))
+                return rc;
+            std::swap(fx, fy);
+        }
+        if ((rc = conv_f32(net, net->policy, fx, FILTERS, count_dev, count_host, max_positions, nullptr, net->policy_out,
+                           net->pol_stride, false, true, st)))
+            return rc;
+        heads_kernel<float><<<max_positions, 64, 0, st>>>(fx, net->heads, count_dev, count_host, nn, net->value, net->ube);
+    }
+    // local uncertainty
+    if (net->has_rnd) {
+        const int in_size = net->cin * nn, in_pad = (in_size + 31) / 32 * 32;
+        float* outs[2] = {net->rnd_out, net->rnd_out + (size_t)net->max_batch * 512};
+        if (bf) {
+            rnd_prep_kernel<__bf16><<<max_positions, 64, 0, st>>>(net->planes, count_dev, count_host, in_size, in_pad, (__bf16*)net->rnd_in);
+            for (int a = 0; a < 2; a++) {
+                if ((rc = conv_bf16(net, net->rnd[a][0], net->rnd_in, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
+                                    net->rnd_h1, 1024, true, false, false, st)))
+                    return rc;
+                if ((rc = conv_bf16(net, net->rnd[a][1], net->rnd_h1, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
+                                    net->rnd_h2, 1024, true, false, false, st)))
+                    return rc;
+                if ((rc = conv_bf16(net, net->rnd[a][2], net->rnd_h2, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
+                                    outs[a], 512, false, true, false, st)))
+                    return rc;
+            }
+        } else {
+            rnd_prep_kernel<float><<<max_positions, 64, 0, st>>>(net->planes, count_dev, count_host, in_size, in_pad, (float*)net->rnd_in);
+            for (int a = 0; a < 2; a++) {
+                if ((rc = conv_f32(net, net->rnd[a][0], (float*)net->rnd_in, in_pad, count_dev, count_host, max_positions, nullptr,
+                                   (float*)net->rnd_h1, 1024, true, false, st)))
+                    return rc;
+                if ((rc = conv_f32(net, net->rnd[a][1], (float*)net->rnd_h1, 1024, count_dev, count_host, max_positions, nullptr,
+                                   (float*)net->rnd_h2, 1024, true, false, st)))
+                    return rc;
+                if ((rc = conv_f32(net, net->rnd[a][2], (float*)net->rnd_h2, 1024, count_dev, count_host, max_positions, nullptr,
+                                   outs[a], 512, false, false, st)))
+                    return rc;
+            }
+        }
+        rnd_finish_kernel<<<max_positions, 64, 0, st>>>(outs[0], outs[1], net->ube, count_dev, count_host, 512, net->rnd_min,
+                                                        net->rnd_max, net->variance);
+    } else if (net->has_hash) {
+        simhash_kernel<<<max_positions, 64, 0, st>>>(net->planes, net->simhash, net->bitset, count_dev, count_host, nn, net->cin,
+                                                     net->aux, nullptr);
+        plain_variance_kernel<<<(max_positions + 255) / 256, 256, 0, st>>>(net->ube, net->aux, count_dev, count_host, net->variance);
+    } else {
+        plain_variance_kernel<<<(max_positions + 255) / 256, 256, 0, st>>>(net->ube, nullptr, count_dev, count_host, net->variance);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("forward launch: ") + hipGetErrorString(e));
+    out->policy = net->policy_out;
+    out->policy_stride = net->pol_stride;
+    out->value = net->value;
+    out->variance = net->variance;
+    return TZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int tz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tz_net_create(int board_n, int arch, int device_id, int precision, int blocks, tz_net** out) {
+    if (!out) return tz_fail(TZ_EINVAL, "tz_net_create: null out");
+    int n = board_n;
+    if (arch == TZ_ARCH_NET5) n = 5;
+    else if (arch == TZ_ARCH_NET4_SIMHASH) n = 4;
+    else if (arch == TZ_ARCH_NET6_SIMHASH) n = 6;
+    else if (arch != TZ_ARCH_TEST) return tz_fail(TZ_EINVAL, "tz_net_create: unknown architecture");
+    if (board_n && board_n != n) return tz_fail(TZ_EINVAL, "tz_net_create: board size does not match the architecture");
+    if (n < 3 || n > 6) return tz_fail(TZ_EINVAL, "tz_net_create: board size must be 3..6");
+    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32) return tz_fail(TZ_EINVAL, "tz_net_create: bad precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return tz_fail(TZ_EDEVICE, "tz_net_create: no HIP device available (the HIP path has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return tz_fail(TZ_EINVAL, "tz_net_create: bad device id");
+    TZ_HIP(hipSetDevice(device_id));
+    tz_net* net = new tz_net();
+    net->n = n;
+    net->nn = n * n;
+    net->arch = arch;
+    net->device = device_id;
+    net->precision = precision;
+    net->blocks = arch == TZ_ARCH_NET5 ? 20 : arch == TZ_ARCH_TEST ? blocks : 16;
+    net->cin = 2 * ((3 + (n - 1) + (n + 1)) + 2) + 2;
+    net->cin_pad = (net->cin + 31) / 32 * 32;
+    net->pol_ch = 3 + 4 * ((1 << n) - 2);
+    net->pol_stride = (net->pol_ch + 127) / 128 * 128;
+    net->ppt = ppt_for(n);
+    net->has_rnd = arch == TZ_ARCH_NET5;
+    net->has_hash = arch == TZ_ARCH_NET4_SIMHASH || arch == TZ_ARCH_NET6_SIMHASH;
+    if (hipStreamCreate(&net->stream) != hipSuccess) {
+        delete net;
+        return tz_fail(TZ_EDEVICE, "tz_net_create: hipStreamCreate failed");
+    }
+    if (net->has_hash) {  // BitBox of 2^32 bits, net6_simhash.rs:138
+        if (hipMalloc(&net->bitset, (size_t)1 << 29) != hipSuccess || hipMemset(net->bitset, 0, (size_t)1 << 29) != hipSuccess) {
+            delete net;
+            return tz_fail(TZ_ENOMEM, "tz_net_create: cannot allocate the 512 MiB SimHash set");
+        }
+    }
+    *out = net;
+    return TZ_OK;
+}
+
+int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
+    if (!net || !data) return tz_fail(TZ_EINVAL, "tz_net_load_weights: null argument");
+    TZ_HIP(hipSetDevice(net->device));
+    TensorMap m;
+    int rc = parse_tzw((const unsigned char*)data, bytes, m);
+    if (rc) return rc;
+    NetWeights W;
+    rc = build_weights(net, m, W);
+    if (rc) {
+        free_weights(W);
+        return rc;  // old weights stay active (selfplay/src/main.rs:112-115)
+    }
+    TZ_HIP(hipStreamSynchronize(net->stream));
+    NetWeights old;
+    old.conv_in = net->conv_in;
+    old.policy = net->policy;
+    old.res = net->res;
+    old.heads = net->heads;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 3; b++) old.rnd[a][b] = net->rnd[a][b];
+    old.simhash = net->simhash;
+    net->conv_in = W.conv_in;
+    net->policy = W.policy;
+    net->res = W.res;
+    net->heads = W.heads;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 3; b++) net->rnd[a][b] = W.rnd[a][b];
+    net->rnd_min = W.rnd_min;
+    net->rnd_max = W.rnd_max;
+    net->simhash = W.simhash;
+    free_weights(old);
+    net->loaded = true;
+    return TZ_OK;
+}
+
+int tz_net_load_weights(tz_net* net, const char* path) {
+    if (!net || !path) return tz_fail(TZ_EINVAL, "tz_net_load_weights: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return tz_fail(TZ_EPARSE, std::string("tz_net_load_weights: cannot open ") + path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> buf(sz > 0 ? sz : 0);
+    const size_t rd = sz > 0 ? fread(buf.data(), 1, sz, f) : 0;
+    fclose(f);
+    if ((long)rd != sz) return tz_fail(TZ_EPARSE, "tz_net_load_weights: short read");
+    return tz_net_load_weights_mem(net, buf.data(), buf.size());
+}
+
+int tz_net_destroy(tz_net* net) {
+    if (!net) return TZ_OK;
+    (void)hipSetDevice(net->device);
+    if (net->stream) (void)hipStreamSynchronize(net->stream);
+    NetWeights old;
+    old.conv_in = net->conv_in;
+    old.policy = net->policy;
+    old.res = net->res;
+    old.heads = net->heads;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 3; b++) old.rnd[a][b] = net->rnd[a][b];
+    old.simhash = net->simhash;
+    free_weights(old);
+    void* bufs[] = {net->act_a, net->act_b, net->act_c, net->planes, net->policy_out, net->value, net->ube,
+                    net->variance, net->aux, net->rnd_in, net->rnd_h1, net->rnd_h2, net->rnd_out, net->bitset};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto& ev : net->conv_events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (net->stream) (void)hipStreamDestroy(net->stream);
+    delete net;
+    return TZ_OK;
+}
+
+static int net_upload_states(tz_net* net, int batch, const tz_state* states, tz_state** dev) {
+    TZ_HIP(hipSetDevice(net->device));
+    int rc = tz_net_ensure_batch(net, batch);
+    if (rc) return rc;
+    TZ_HIP(hipMalloc(dev, (size_t)batch * sizeof(tz_state)));
+    TZ_HIP(hipMemcpyAsync(*dev, states, (size_t)batch * sizeof(tz_state), hipMemcpyHostToDevice, net->stream));
+    return TZ_OK;
+}
+
+int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* legal_idx, const int32_t* legal_count,
+                int amax, float* logits_out, float* value_out, float* variance_out) {
+    if (!net || !states || !legal_idx || !legal_count || !logits_out || !value_out || !variance_out)
+        return tz_fail(TZ_EINVAL, "tz_net_eval: null argument");
+    if (batch <= 0 || amax <= 0) return tz_fail(TZ_EINVAL, "tz_net_eval: empty batch (net5.rs:226-227 asserts)");
+    for (int b = 0; b < batch; b++) {
+        if (states[b].n != net->n) return tz_fail(TZ_EINVAL, "tz_net_eval: state board size does not match the network");
+        if (legal_count[b] < 0 || legal_count[b] > amax) return tz_fail(TZ_EINVAL, "tz_net_eval: legal_count out of range");
+        for (int j = 0; j < legal_count[b]; j++)
+            if (legal_idx[(size_t)b * amax + j] >= net->pol_ch * net->nn)
+                return tz_fail(TZ_EINVAL, "tz_net_eval: move index out of range");
+    }
+    tz_state* dstates = nullptr;
+    int rc = net_upload_states(net, batch, states, &dstates);
+    if (rc) return rc;
+    uint16_t* dlegal = nullptr;
+    int32_t* dcnt = nullptr;
+    float* dlog = nullptr;
+    hipStream_t st = net->stream;
+    auto cleanup = [&]() {
+        (void)hipFree(dstates);
+        if (dlegal) (void)hipFree(dlegal);
+        if (dcnt) (void)hipFree(dcnt);
+        if (dlog) (void)hipFree(dlog);
+    };
+    NetOut o;
+    rc = tz_net_forward_device(net, dstates, nullptr, nullptr, batch, batch, st, &o);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    const size_t cells = (size_t)batch * amax;
+    if (hipMalloc(&dlegal, cells * 2) != hipSuccess || hipMalloc(&dcnt, batch * 4) != hipSuccess ||
+        hipMalloc(&dlog, cells * 4) != hipSuccess) {
+        cleanup();
+        return tz_fail(TZ_ENOMEM, "tz_net_eval: device allocation failed");
+    }
+    hipError_t e = hipMemcpyAsync(dlegal, legal_idx, cells * 2, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dcnt, legal_count, batch * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        gather_kernel<<<(int)((cells + 255) / 256), 256, 0, st>>>(o.policy, net->nn, o.policy_stride, dlegal, dcnt, amax, batch, dlog);
+        e = hipMemcpyAsync(logits_out, dlog, cells * 4, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(value_out, o.value, batch * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(variance_out, o.variance, batch * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tz_net_eval: ") + hipGetErrorString(e));
+    for (size_t i = 0; i < cells; i++)
+        if (logits_out[i] != logits_out[i]) return tz_fail(TZ_ENUMERIC, "tz_net_eval: NaN logit (net5.rs:263 panics)");
+    return TZ_OK;
+}
+
+int tz_net_encode(tz_net* net, int batch, const tz_state* states, float* planes_out) {
+    if (!net || !states || !planes_out || batch <= 0) return tz_fail(TZ_EINVAL, "tz_net_encode: bad argument");
+    tz_state* dstates = nullptr;
+    int rc = net_upload_states(net, batch, states, &dstates);
+    if (rc) return rc;
+    hipStream_t st = net->stream;
+    rc = encode(net, dstates, nullptr, nullptr, batch, batch, st);
+    float* dout = nullptr;
+    const size_t total = (size_t)batch * net->cin * net->nn;
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMalloc(&dout, total * 4);
+        if (e == hipSuccess) {
+            planes_nchw_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(net->planes, net->nn, net->cin, batch, dout);
+            e = hipMemcpyAsync(planes_out, dout, total * 4, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(dstates);
+    if (dout) (void)hipFree(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tz_net_encode: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+int tz_net_forward_raw(tz_net* net, int batch, const tz_state* states, float* policy_out, float* value_out, float* ube_out) {
+    if (!net || !states || batch <= 0) return tz_fail(TZ_EINVAL, "tz_net_forward_raw: bad argument");
+    tz_state* dstates = nullptr;
+    int rc = net_upload_states(net, batch, states, &dstates);
+    if (rc) return rc;
+    hipStream_t st = net->stream;
+    NetOut o;
+    rc = tz_net_forward_device(net, dstates, nullptr, nullptr, batch, batch, st, &o);
+    float* dout = nullptr;
+    hipError_t e = hipSuccess;
+    const size_t total = (size_t)batch * net->pol_ch * net->nn;
+    if (!rc) {
+        if (policy_out) {
+            e = hipMalloc(&dout, total * 4);
+            if (e == hipSuccess) {
+                policy_nchw_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(o.policy, net->nn, o.policy_stride, net->pol_ch, batch, dout);
+                e = hipMemcpyAsync(policy_out, dout, total * 4, hipMemcpyDeviceToHost, st);
+            }
+        }
+        if (e == hipSuccess && value_out) e = hipMemcpyAsync(value_out, net->value, batch * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && ube_out) e = hipMemcpyAsync(ube_out, net->ube, batch * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(dstates);
+    if (dout) (void)hipFree(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tz_net_forward_raw: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+"""End-to-end parity: the HIP engine (tree kernels + MFMA net on the device, no host round trip
+inside a simulation) against the CPU oracle search whose agent is the *same* HIP network called
+through tz_net_eval.  With identical priors on both sides visit counts and chosen moves must be
+equal (north_star: 'visit counts and chosen moves matching ... under a fixed RNG seed')."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_util import require_gpu
+from test_gpu_tree import assert_same_roots
+
+pytestmark = pytest.mark.gpu
+
+
+def _agent_over(net):
+    def fn(user, n_envs, states, legal_idx, legal_count, amax, logits_out, value_out, variance_out):
+        rc = net.lib.tz_net_eval(net.h, n_envs, C.cast(states, C.c_void_p), C.cast(legal_idx, C.c_void_p),
+                                 C.cast(legal_count, C.c_void_p), amax, C.cast(logits_out, C.c_void_p),
+                                 C.cast(value_out, C.c_void_p), C.cast(variance_out, C.c_void_p))
+        assert rc == 0, net.lib.tz_last_error()
+    return fn
+
+
+@pytest.mark.parametrize("arch,n,blocks,prec,B,sims,moves", [(100, 5, 2, 0, 24, 30, 5), (100, 4, 1, 1, 16, 25, 4),
+                                                             (5, 5, 20, 0, 12, 24, 3)])
+def test_engine_matches_oracle_search_with_same_net(oracle, arch, n, blocks, prec, B, sims, moves):
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    net = A.Net(arch=arch, n=n, precision=prec, blocks=blocks)
+    net.load_tensors(W.init_weights(arch, n=n, blocks=blocks, seed=123))
+    gpu = A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 14)
+    ora = O.OracleSearch(oracle, B, n, 4, agent_kind=0, agent_fn=_agent_over(net))
+    rng = np.random.default_rng(2024)
+    choice = rng.integers(0, 16, B)
+    gpu.new_openings(choice)
+    ora.new_openings(choice)
+    betas = np.where(np.arange(B) % 2 == 0, 0.25, 0.0).astype(np.float32)
+    for mv in range(moves):
+        gpu.simulate(betas, 1)
+        ora.simulate(betas, 1)
+        info = ora.root_info()
+        amax = max(1, int(info["n_children"].max()))
+        noise = np.zeros((B, amax), np.float32)
+        for g in range(B):
+            noise[g, :info["n_children"][g]] = rng.dirichlet([0.05] * int(info["n_children"][g])).astype(np.float32)
+        gpu.apply_noise(noise, 0.2)
+        ora.apply_noise(noise, 0.2)
+        gpu.simulate(betas, sims)
+        ora.simulate(betas, sims)
+        assert_same_roots(gpu, ora, "move %d" % mv)
+        acts = gpu.select_best_actions()
+        assert np.array_equal(acts, ora.select_best_actions())
+        gpu.step(acts)
+        ora.step(acts)
+        choice = rng.integers(0, 16, B)
+        assert np.array_equal(gpu.restart_terminal_envs(choice), ora.restart_terminal(choice))
+    assert gpu.counters() == ora.counters()

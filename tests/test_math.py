@@ -32,7 +32,15 @@ def test_expf_logf_agree_with_libm(oracle):
         if a != b:
             bad += 1
             assert abs(np.float32(a).view(np.int32).astype(np.int64) - np.float32(b).view(np.int32)) <= 1, y
-    assert bad <= len(ys) // 1000, bad
+    # glibc's logf documents 0.818 ulp, so 1-ulp disagreements are expected there; tz_logf itself must
+    # be the correctly rounded value (checked against float64 below)
+    assert bad <= len(ys) // 50, bad
+    exact = np.log(ys.astype(np.float64)).astype(np.float32)
+    mine = np.array([oracle.tzo_logf(float(y)) for y in ys], np.float32)
+    assert np.count_nonzero(mine != exact) <= 2
+    exact = np.exp(xs.astype(np.float64)).astype(np.float32)
+    mine = np.array([oracle.tzo_expf(float(x)) for x in xs], np.float32)
+    assert np.count_nonzero(mine != exact) <= 2
     assert oracle.tzo_expf(0.0) == 1.0 and oracle.tzo_logf(1.0) == 0.0
     assert oracle.tzo_expf(-200.0) == 0.0 and math.isinf(oracle.tzo_logf(0.0))
 
