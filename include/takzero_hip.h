@@ -205,6 +205,10 @@ int tz_search_sync(tz_search* s);
 int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_launches,
                       double* tree_ms, uint64_t* steps);
 
+/* Diagnostic: evaluates on the device the f32 primitives the tree kernels must compute exactly as
+ * the host does (op 0 exp, 1 ln, 2 sqrt, 3 a/b, 4 0.997^int(a), 5 (a+b)*a). */
+int tz_device_math(int op, const float* a, const float* b, float* out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,7 +160,7 @@ __device__ void backup(const SearchDev& s, size_t base, const uint32_t* tnode, c
             float mean = tz_bits_to_float(ev.bits);
             mean = mean + (-mean + negated) / n;
             ev = ev_value(mean);
-            sd = sd + (-sd + __fsqrt_rn(child_var)) / n;
+            sd = sd + (-sd + sqrtf(child_var)) / n;
             up = ev_value(negated * TZ_DISCOUNT);
             up_var = child_var * TZ_DISCOUNT * TZ_DISCOUNT;
         }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void descend_kernel(SearchDev s, int from_start
         const uint32_t c0 = s.t.child0[base + node];
         const float parent = (float)vis;
         const float er = tz_logf(((1.0f + parent) + 500.0f) / 500.0f) + 4.0f;  // policy.rs:143-145
-        const float sq = __fsqrt_rn(parent);
+        const float sq = sqrtf(parent);
         const bool parent_loss = ev.tag == TZ_EVAL_LOSS;
         float best_score = 0.0f;
         int best_i = -1;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64) void expand_kernel(SearchDev s, NetOut out) {
     float mean = tz_bits_to_float(s.t.eval_bits[base + leaf]);
     mean = mean + (-mean + value) / n;
     float sd = s.t.std_dev[base + leaf];
-    sd = sd + (-sd + __fsqrt_rn(variance)) / n;
+    sd = sd + (-sd + sqrtf(variance)) / n;
     const uint32_t c0 = s.alloc[g];
     if (c0 + (uint32_t)nact > (uint32_t)s.cap) {
         if (l == 0) atomicMax(s.error_flag, 1);
@@ -748,11 +748,41 @@ __global__ __launch_bounds__(64) void gumbel_fixup_kernel(SearchDev s) {
         default: return tz_fail(TZ_EINVAL, "unsupported board size"); \
     }
 
+// diagnostic: the f32 primitives the tree kernels rely on being bit-identical with the host
+__global__ void device_math_kernel(int op, const float* a, const float* b, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (op) {
+        case 0: out[i] = tz_expf(a[i]); break;
+        case 1: out[i] = tz_logf(a[i]); break;
+        case 2: out[i] = sqrtf(a[i]); break;
+        case 3: out[i] = a[i] / b[i]; break;
+        case 4: out[i] = tz_powif(TZ_DISCOUNT, (int)a[i]); break;
+        default: out[i] = (a[i] + b[i]) * a[i]; break;
+    }
+}
+
 #define TZ_LAUNCH_CHECK()                                                                       \
     do {                                                                                        \
         hipError_t _e = hipGetLastError();                                                      \
         if (_e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(_e)); \
     } while (0)
+
+extern "C" int tz_device_math(int op, const float* a, const float* b, float* out, int n) {
+    if (!a || !b || !out || n <= 0) return tz_fail(TZ_EINVAL, "tz_device_math: bad argument");
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    TZ_HIP(hipMalloc(&da, n * 4));
+    TZ_HIP(hipMalloc(&db, n * 4));
+    TZ_HIP(hipMalloc(&dout, n * 4));
+    TZ_HIP(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    TZ_HIP(hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    device_math_kernel<<<(n + 255) / 256, 256>>>(op, da, db, dout, n);
+    TZ_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    return TZ_OK;
+}
 
 int tz_tree_descend(const SearchDev& s, bool from_start_nodes, hipStream_t st) {
     TZ_DISPATCH_N(s.n, (descend_kernel<NB><<<s.batch, 64, 0, st>>>(s, from_start_nodes ? 1 : 0)));

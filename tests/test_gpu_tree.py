@@ -194,3 +194,35 @@ def test_capacity_error_is_reported(oracle):
     with pytest.raises(A.TakzeroError) as e:
         gpu.simulate(np.zeros(4, np.float32), 20)
     assert e.value.code == -5
+
+
+def test_device_f32_primitives_match_host(oracle):
+    """exp / ln / sqrt / divide / powi on the device are bit-identical with the host versions the oracle uses."""
+    A = require_gpu()
+    import ctypes as C
+    lib = A._lib.load()
+    rng = np.random.default_rng(0)
+    n = 200000
+    a = np.concatenate([rng.random(n // 2, dtype=np.float32) * 4, rng.random(n // 2, dtype=np.float32) * 1e-3]).astype(np.float32)
+    b = (rng.random(n, dtype=np.float32) * 1000 + np.float32(1e-3)).astype(np.float32)
+    out = np.zeros(n, np.float32)
+
+    def run(op, x, y):
+        x, y = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)
+        A.check(lib.tz_device_math(op, x.ctypes.data, y.ctypes.data, out.ctypes.data, len(x)))
+        return out[:len(x)].copy()
+
+    neg = -a * 10
+    got = run(0, neg, b)
+    want = np.array([oracle.tzo_expf(float(v)) for v in neg[:20000]], np.float32)
+    assert np.array_equal(got[:20000].view(np.uint32), want.view(np.uint32))
+    got = run(1, b, b)
+    want = np.array([oracle.tzo_logf(float(v)) for v in b[:20000]], np.float32)
+    assert np.array_equal(got[:20000].view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(run(2, a, b).view(np.uint32), np.sqrt(a).view(np.uint32))
+    assert np.array_equal(run(3, a, b).view(np.uint32), (a / b).view(np.uint32))
+    k = np.arange(0, 600, dtype=np.float32)
+    got = run(4, k, k)
+    want = np.array([oracle.tzo_powif(0.997, int(v)) for v in k], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(run(5, a, b).view(np.uint32), ((a + b) * a).view(np.uint32))
