@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — self-play throughput of the MI355X engine on BASELINE.json's north-star configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (configs[1]): 5x5 Tak, half-komi 4, 4096 concurrent games per GPU,
+400 simulations per move, classic PUCT + Dirichlet(alpha 0.05, ratio 0.2), beta 0, net5 (20 residual
+blocks x 256 filters + RND) with random-init weights (seed 123), synthetic openings.  One "step" is one
+self-play move for every game of the shard: 1 root expansion + 400 lock-step simulations, move choice,
+subtree-reuse step, restart of finished games, target completion.  Everything a simulation needs
+(tree descent, move generation, plane encoding, the net forward, expansion, backup) runs on the GPU with
+positions resident in HBM; per move the host only draws the Dirichlet noise and reads root statistics.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), independent shards of 4096 games
+(weak scaling), and after every move an all-gather of the finished games' target records — the only
+collective on the path.
+
+Prints ONE JSON line (rank 0).  `value` = MCTS simulations/s summed over all ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_BOARD, HALF_KOMI, GAMES, SIMS = 5, 4, 4096, 400
+FLOP_PER_POSITION = 1.2071e9          # net5, SURVEY.md §8d
+CONV_FLOP_PER_POSITION = 2 * 25 * 256 * 2304   # one 3x3 256->256 conv on one 5x5 board (the dominant kernel)
+PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
+
+
+def cpu_baseline(seconds=12.0):
+    """Stand-in for the reference's CPU tch path: the single-threaded CPU oracle search
+    (oracle/, restating batched.rs:63-128) driving a LibTorch CPU forward of the same net5 graph, 128 games
+    (the reference's BATCH_SIZE).  Returns sims/s on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+
+    import nets_torch as T
+    import oracle_lib as O
+    from takzero_amd import weights as W
+
+    lib = O.load()
+    w = W.init_weights(W.ARCH_NET5, seed=123)
+    B = 128
+
+    def agent(user, n_envs, states, legal_idx, legal_count, amax, logits_out, value_out, variance_out):
+        planes = np.zeros((n_envs, 32 * 25), np.float32)
+        for i in range(n_envs):
+            lib.tzo_game_repr(C.byref(states[i]), planes[i].ctypes.data_as(C.POINTER(C.c_float)))
+        planes = planes.reshape(n_envs, 32, 5, 5)
+        pol, val, ube = T.forward(w, planes, 20)
+        var = T.variance(w, planes, ube, 5)
+        pol = pol.reshape(n_envs, -1).numpy()
+        for i in range(n_envs):
+            k = legal_count[i]
+            idx = np.ctypeslib.as_array(legal_idx, shape=(n_envs * amax,))[i * amax:i * amax + k]
+            np.ctypeslib.as_array(logits_out, shape=(n_envs * amax,))[i * amax:i * amax + k] = pol[i, idx]
+            value_out[i] = float(val[i])
+            variance_out[i] = float(var[i])
+
+    s = O.OracleSearch(lib, B, N_BOARD, HALF_KOMI, agent_kind=0, agent_fn=agent)
+    rng = np.random.default_rng(0)
+    s.new_openings(rng.integers(0, 16, B))
+    betas = np.zeros(B, np.float32)
+    s.simulate(betas, 1)  # root expansion, untimed warm-up of torch
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds or steps < 2:
+        s.simulate(betas, 1)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=B * steps / dt, unit="sims/s", cores=int(torch.get_num_threads()), kind="port",
+                sample="%d lock-step simulations of 128 games (5x5, net5 fp32 on LibTorch CPU, oracle search single-threaded), %.1f s"
+                       % (steps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games", type=int, default=GAMES)
+    ap.add_argument("--sims", type=int, default=SIMS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--capacity", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import takzero_amd.api as A
+    from takzero_amd import selfplay as SP
+    from takzero_amd import weights as W
+
+    net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_BF16)
+    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
+    mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
+    sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank)
+    dev = "cuda:%d" % local_rank
+
+    def barrier():
+        mcts.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    gathered = 0
+    for _ in range(args.warmup):
+        t, _r = sp.play_move()
+        gathered += len(SP.all_gather_targets(t, N_BOARD, dev) if dist is not None else t)
+    barrier()
+    mcts.profile(reset=2 if args.no_profile else 1)
+    sims0, evals0 = mcts.counters()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t, _r = sp.play_move()
+        gathered += len(SP.all_gather_targets(t, N_BOARD, dev) if dist is not None else t)
+    barrier()
+    dt = time.perf_counter() - t0
+    sims1, evals1 = mcts.counters()
+    prof = mcts.profile(reset=2)
+
+    local = np.array([dt, sims1 - sims0, evals1 - evals0, args.games * args.steps], dtype=np.float64)
+    if dist is not None:
+        tl = torch.tensor(local, device=dev)
+        tmax = tl.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+        dt_max = float(tmax[0])
+        sims, evals, positions = float(tl[1]), float(tl[2]), float(tl[3])
+    else:
+        dt_max, sims, evals, positions = dt, local[1], local[2], local[3]
+
+    if rank == 0:
+        out = {
+            "metric": "mcts_simulations_per_s",
+            "value": sims / dt_max,
+            "unit": "sims/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt_max / max(1, args.steps),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (random-init net5 weights seed 123, random symmetric openings)",
+            "config": {"workload": "5x5 Tak self-play, %d concurrent games/GPU, %d sims/move, PUCT+Dirichlet, net5 (BASELINE configs[1])"
+                                   % (args.games, args.sims),
+                       "games_per_gpu": args.games, "sims_per_move": args.sims, "parallelism": "shard%d" % world},
+            "selfplay_positions_per_s": positions / dt_max,
+            "nn_leaf_evals_per_s": evals / dt_max,
+            "targets_gathered": gathered,
+        }
+        if not args.no_profile and prof["conv_launches"]:
+            per_launch_positions = (evals1 - evals0) / max(1, prof["steps"])
+            flop_per_launch = CONV_FLOP_PER_POSITION * per_launch_positions
+            avg_ms = prof["conv_ms"] / prof["conv_launches"]
+            achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                               "kernel": "conv_mfma_kernel<5,8,2,9,false> (3x3 256->256 residual-tower conv)",
+                               "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
+                               "positions_per_launch": per_launch_positions}
+            out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
+                                            "tower_convs": prof["conv_ms"] / max(1, prof["steps"]),
+                                            "wall": 1000.0 * dt / max(1.0, (sims1 - sims0) / args.games)}
+            out["net_flops_frac_of_peak"] = (evals / dt_max) * FLOP_PER_POSITION / (world * PEAK_BF16_TFLOPS * 1e12)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the checker must not take the measurement down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    mcts.close()
+    net.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

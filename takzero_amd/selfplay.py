@@ -1,0 +1,190 @@
+"""Self-play driver over BatchedMCTS — the outer loop of the reference's `selfplay` binary
+(selfplay/src/main.rs:63-205, 238-329) for the classic PUCT + Dirichlet search the north star names
+(the driver lines at selfplay/src/main.rs:127-136, live library code batched.rs:63-183) and for
+Gumbel sequential halving (selfplay/src/main.rs:138-153).
+
+One SelfPlay object drives one GPU's shard of games.  Randomness (openings, Dirichlet / Gumbel
+noise, early-ply move sampling) is drawn here from a counter-keyed numpy generator so that a CPU
+run of the oracle can be fed the same values."""
+import numpy as np
+
+from . import api
+
+NOISE_ALPHA = 0.05   # selfplay/src/main.rs:39
+NOISE_RATIO = 0.2    # selfplay/src/main.rs:40
+WEIGHTED_RANDOM_PLIES = 10  # selfplay/src/main.rs:38
+BETA = 0.25          # selfplay/src/main.rs:41
+
+
+def dirichlet_rows(rng, counts, alpha, amax):
+    """One symmetric Dir(alpha) sample per row, of dimension counts[row], zero padded to amax."""
+    B = len(counts)
+    g = rng.standard_gamma(alpha, size=(B, amax)).astype(np.float64)
+    mask = np.arange(amax)[None, :] < np.asarray(counts)[:, None]
+    g = np.where(mask, g, 0.0)
+    s = g.sum(axis=1, keepdims=True)
+    # a row whose gammas all underflowed: put the mass on one child (what a Dirichlet with tiny alpha tends to)
+    dead = (s[:, 0] <= 0) & (np.asarray(counts) > 0)
+    if dead.any():
+        g[dead, 0] = 1.0
+        s = g.sum(axis=1, keepdims=True)
+    s[s == 0] = 1.0
+    return (g / s).astype(np.float32)
+
+
+class SelfPlay:
+    def __init__(self, mcts, sims_per_move, seed=0, shard=0, betas=None, search="puct", sampled_actions=64,
+                 collect_targets=True):
+        self.mcts = mcts
+        self.sims = sims_per_move
+        self.search = search
+        self.k = sampled_actions
+        self.rng = np.random.default_rng([seed, shard])
+        self.betas = np.zeros(mcts.batch, np.float32) if betas is None else np.asarray(betas, np.float32)
+        self.collect = collect_targets
+        self.pending = [[] for _ in range(mcts.batch)]   # IncompleteTarget lists, selfplay/src/main.rs:230-236
+        self.replays = [[] for _ in range(mcts.batch)]
+        self.start_states = None
+        self.moves_played = 0
+        self.positions = 0
+        mcts.new_openings(self.rng.integers(0, 16, mcts.batch))
+        if self.collect:
+            self.start_states = mcts.get_positions()
+
+    def play_move(self):
+        """One outer-loop iteration of selfplay::main.  Returns (finished_targets, finished_replays)."""
+        m, B = self.mcts, self.mcts.batch
+        if self.search == "puct":
+            m.simulate(self.betas, 1)                       # selfplay/src/main.rs:128
+            info = m.root_info()
+            amax = max(1, int(info["n_children"].max()))
+            noise = dirichlet_rows(self.rng, info["n_children"], NOISE_ALPHA, amax)
+            m.apply_noise(noise, NOISE_RATIO)               # :131
+            m.simulate(self.betas, self.sims)               # :134-136
+            actions = m.select_actions_in_selfplay(self.rng, WEIGHTED_RANDOM_PLIES)  # batched.rs:165-183
+        else:
+            gumbel = self.rng.gumbel(size=(B, 512 if m.n < 6 else 1024)).astype(np.float32)
+            actions = m.gumbel_sequential_halving(self.betas, self.k, self.sims, gumbel)  # :138-144
+        targets, replays = [], []
+        if self.collect:
+            self._record(actions)
+        m.step(actions)                                     # take_a_step, :238-258
+        term = m.restart_terminal_envs(self.rng.integers(0, 16, B))  # :263-329
+        if self.collect:
+            targets, replays = self._complete(term)
+        self.moves_played += 1
+        self.positions += B
+        return targets, replays
+
+    # ---- target bookkeeping (host side, trivial cost: SURVEY.md §8a rows a22-a23)
+    def _record(self, actions):
+        m = self.mcts
+        info = m.root_info()
+        ch = m.root_children()
+        states = m.get_positions()
+        if self.search == "puct":
+            vis = ch["visits"].astype(np.float32)
+            pol = vis / np.maximum(info["visit_count"].astype(np.float32), 1)[:, None]  # target.rs:151-164
+        else:
+            lg = int(np.log2(self.k))
+            visitations = (self.sims // lg // self.k) * (2 ** lg - 1)  # selfplay/src/main.rs:47-52
+            pol = m.improved_policy(float(visitations), ch["visits"].shape[1])
+        ube = m.ube_target(BETA)
+        for g in range(m.batch):
+            if info["eval_tag"][g] != api.EVAL_VALUE and info["eval_bits"][g] == 0:
+                continue  # terminal roots are not stepped (batched.rs:137)
+            nc = int(info["n_children"][g])
+            self.pending[g].append((states[g].copy(), ch["move_idx"][g, :nc].copy(), pol[g, :nc].copy(), float(ube[g])))
+            self.replays[g].append(int(actions[g]))
+
+    def _complete(self, term):
+        targets, replays = [], []
+        new_states = None
+        for g in np.nonzero(term != api.TERMINAL_NONE)[0]:
+            # value walks back from the terminal Eval, negating at every step (selfplay/src/main.rs:294-326)
+            tag = {api.TERMINAL_WIN: api.EVAL_WIN, api.TERMINAL_LOSS: api.EVAL_LOSS, api.TERMINAL_DRAW: api.EVAL_DRAW}[int(term[g])]
+            ply = 0
+            for state, moves, pol, ube in reversed(self.pending[g]):
+                tag = {api.EVAL_WIN: api.EVAL_LOSS, api.EVAL_LOSS: api.EVAL_WIN, api.EVAL_DRAW: api.EVAL_DRAW}[tag]
+                ply += 1
+                value = float(api.eval_to_f32(tag, ply))
+                if self.betas[g] == 0.0 or state["ply"] > WEIGHTED_RANDOM_PLIES:
+                    targets.append((state, moves, pol, value, ube))
+            replays.append((self.start_states[g].copy(), list(self.replays[g]), int(term[g])))
+            self.pending[g] = []
+            self.replays[g] = []
+            if new_states is None:
+                new_states = self.mcts.get_positions()
+            self.start_states[g] = new_states[g]
+        return targets, replays
+
+
+# ---------------------------------------------------------------------------------------------
+# fixed-stride packed target records for the RCCL all-gather into `learn`
+def record_stride(n):
+    amax = 512 if n < 6 else 1024
+    return 376 + 4 + 4 + 4 + amax * 6
+
+
+def pack_targets(targets, n):
+    stride = record_stride(n)
+    amax = 512 if n < 6 else 1024
+    out = np.zeros((len(targets), stride), np.uint8)
+    for i, (state, moves, pol, value, ube) in enumerate(targets):
+        row = out[i]
+        row[:376] = np.frombuffer(state.tobytes(), np.uint8)
+        row[376:380] = np.frombuffer(np.float32(value).tobytes(), np.uint8)
+        row[380:384] = np.frombuffer(np.float32(ube).tobytes(), np.uint8)
+        k = min(len(moves), amax)
+        row[384:388] = np.frombuffer(np.uint32(k).tobytes(), np.uint8)
+        row[388:388 + 2 * k] = np.frombuffer(np.ascontiguousarray(moves[:k], np.uint16).tobytes(), np.uint8)
+        off = 388 + 2 * amax
+        row[off:off + 4 * k] = np.frombuffer(np.ascontiguousarray(pol[:k], np.float32).tobytes(), np.uint8)
+    return out
+
+
+def unpack_targets(buf, n):
+    amax = 512 if n < 6 else 1024
+    out = []
+    for row in buf:
+        state = np.frombuffer(row[:376].tobytes(), api.STATE_DTYPE)[0]
+        value = np.frombuffer(row[376:380].tobytes(), np.float32)[0]
+        ube = np.frombuffer(row[380:384].tobytes(), np.float32)[0]
+        k = int(np.frombuffer(row[384:388].tobytes(), np.uint32)[0])
+        moves = np.frombuffer(row[388:388 + 2 * k].tobytes(), np.uint16)
+        off = 388 + 2 * amax
+        pol = np.frombuffer(row[off:off + 4 * k].tobytes(), np.float32)
+        out.append((state, moves, pol, float(value), float(ube)))
+    return out
+
+
+def all_gather_targets(targets, n, device=None):
+    """All ranks contribute their finished targets; every rank receives all of them.  Collective:
+    torch.distributed all_gather of counts, then of zero-padded fixed-stride records (NCCL = RCCL over
+    xGMI on the GPU box, gloo on CPU).  No collective runs inside the search itself."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return targets
+    world = dist.get_world_size()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    packed = pack_targets(targets, n)
+    cnt = torch.tensor([len(targets)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    if mx == 0:
+        return []
+    stride = record_stride(n)
+    local = torch.zeros((mx, stride), dtype=torch.uint8, device=dev)
+    if len(targets):
+        local[:len(targets)] = torch.from_numpy(packed).to(dev)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    out = []
+    for r in range(world):
+        if counts[r]:
+            out.extend(unpack_targets(gathered[r][:counts[r]].cpu().numpy(), n))
+    return out
