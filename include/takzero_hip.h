@@ -208,6 +208,9 @@ int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_l
 /* Diagnostic: evaluates on the device the f32 primitives the tree kernels must compute exactly as
  * the host does (op 0 exp, 1 ln, 2 sqrt, 3 a/b, 4 0.997^int(a), 5 (a+b)*a). */
 int tz_device_math(int op, const float* a, const float* b, float* out, int n);
+/* Diagnostic: average ms per launch of the 5x5 residual-tower conv kernel on `positions` boards;
+ * variant 0 = the shipped kernel, 1/2/3 = ablations (no LDS reads / no weight loads / neither). */
+int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDS_STRIDE = 528;  // bytes per LDS row: 256 bf16 + 16 B pad (bank spread for ds_read_b128)
 constexpr int FILTERS = 256;
@@ -101,102 +102,191 @@ struct ConvArgs {
 // Implicit-GEMM convolution on MFMA.  Tile = P boards x (128*RN) output channels per workgroup,
 // 8 waves split the output channels (16*RN each) so each wave's weight fragments are private and
 // come straight from global memory; the activation tile is shared through LDS.
-template <int NB, int P, int RN, int TAPS, bool FROM_STATE>
+// per-tap LDS byte offsets of a lane's 16-row fragments (row-shifted reads; off-board taps -> zero row)
+template <int NB, int RT, int TAPS>
+__device__ __forceinline__ void tap_bases(const int (&yx)[RT], int tap, int lr, int q, int zrow, int (&abase)[RT]) {
+    const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int y = (yx[rt] & 0xff) + dy, x = (yx[rt] >> 8) + dx;
+        const bool ok = y >= 0 && y < NB && x >= 0 && x < NB;
+        const int sr = ok ? rt * 16 + lr + dy * NB + dx : zrow;
+        abase[rt] = sr * LDS_STRIDE + q * 16;
+    }
+}
+
+template <int NB, int RT, int TAPS>
+__device__ __forceinline__ void tap_bases_rc(int tap, int lr, int q, int rows, int zrow, int (&abase)[RT]) {
+    constexpr int NN = NB * NB;
+    const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int r = rt * 16 + lr, px = r % NN;
+        const int y = px / NB + dy, x = px % NB + dx;
+        const bool ok = r < rows && y >= 0 && y < NB && x >= 0 && x < NB;
+        const int sr = ok ? r + dy * NB + dx : zrow;
+        abase[rt] = sr * LDS_STRIDE + q * 16;
+    }
+}
+
+// ABL (diagnostic builds only, tz_debug_conv_bench): 1 = no LDS fragment reads, 2 = no weight loads, 3 = neither.
+// SINGLE: the whole reduction is one 256-channel slice (tower and policy convs): unrolled tile loader,
+// weight fragments prefetched two k-steps ahead.
+template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false>
 __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
     constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 1, ZROW = RT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int count = a.count_dev ? *a.count_dev : a.count_host;
     const int pos0 = blockIdx.x * P;
     if (pos0 >= count) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: weight addresses stay in SGPRs
     const int q = lane >> 4, lr = lane & 15;
     const int valid_rows = min(ROWS, (count - pos0) * NN);
     const size_t m0 = (size_t)pos0 * NN;
-
-    int yx[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-        const int r = rt * 16 + lr;
-        const int px = r % NN;
-        yx[rt] = r < ROWS ? ((px / NB) | ((px % NB) << 8)) : 0x7f7f;
-    }
-    f32x4 acc[RT][RN];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-        for (int j = 0; j < RN; j++) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int ct0 = (blockIdx.y * 8 + wave) * RN;
-    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(a.w) + lane;
-    auto wptr = [&](int tap, int kcg, int j) -> const bf16x8* {
-        return wfrag + ((size_t)(tap * a.kc_total + kcg) * a.ct_total + (ct0 + j)) * 64;
+    // fragment (tap, k-chunk, col tile) = 64 lanes x 16 B.  Buffer loads: descriptor + scalar fragment
+    // offset in SGPRs, one VGPR (lane*16) for all of them -> no per-fragment 64-bit address registers.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.w), 0, TAPS * a.kc_total * a.ct_total * 1024, 0x00020000);
+    const int lane16 = lane * 16;
+    auto wload = [&](int tap, int kcg, int j) -> bf16x8 {
+        const int frag = (tap * a.kc_total + kcg) * a.ct_total + (ct0 + j);
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0);
+        return __builtin_bit_cast(bf16x8, r);
     };
+    f32x4 acc[RT][RN];
 
-    const int nslices = (a.cin_pad + 255) / 256;
-    for (int slice = 0; slice < nslices; slice++) {
-        const int cs = min(256, a.cin_pad - slice * 256);
-        const int kcs = cs / 32, cpr = cs / 8;
-        __syncthreads();
-        if constexpr (FROM_STATE) {
-            // game_repr fused into the tile loader: one thread per (board, square)
-            if (tid < LROWS) {
-                const int row = tid;
-                const bool ok = row < valid_rows;
-                const tz_state* s = nullptr;
-                int px = 0, fd = 0;
-                if (ok) {
-                    const int pos = pos0 + row / NN;
-                    px = row % NN;
-                    s = a.states + (a.game_index ? a.game_index[pos] : pos);
-                    fd = state_flat_diff<NB>(s);
-                }
-                for (int c8 = 0; c8 < cpr; c8++) {
-                    bf16x8 v;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int c = c8 * 8 + k;
-                        v[k] = (__bf16)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
-                    }
-                    *reinterpret_cast<bf16x8*>(lds + row * LDS_STRIDE + c8 * 16) = v;
-                }
-            }
-        } else {
+    if constexpr (SINGLE) {
+        static_assert(!FROM_STATE, "SINGLE is for bf16 activations");
+        {   // every load of the tile is in flight before the first LDS store: one memory round trip
             const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
-            for (int id = tid; id < LROWS * cpr; id += 512) {
-                const int row = id / cpr, ci = id % cpr;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (row < valid_rows)
-                    v = *reinterpret_cast<const uint4*>(in + (m0 + row) * a.cin_pad + slice * 256 + ci * 8);
-                *reinterpret_cast<uint4*>(lds + row * LDS_STRIDE + ci * 16) = v;
+            constexpr int NLOAD = (LROWS * 32 + 511) / 512;
+            uint4 v[NLOAD];
+#pragma unroll
+            for (int i = 0; i < NLOAD; i++) {
+                const int id = tid + i * 512, row = id >> 5, ci = id & 31;
+                v[i] = make_uint4(0, 0, 0, 0);
+                if (row < valid_rows) v[i] = *reinterpret_cast<const uint4*>(in + (m0 + row) * 256 + ci * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NLOAD; i++) {
+                const int id = tid + i * 512, row = id >> 5, ci = id & 31;
+                if (row < LROWS) *reinterpret_cast<uint4*>(lds + row * LDS_STRIDE + ci * 16) = v[i];
             }
         }
+        // weight ring: 4 slots, slot = kc & 3 (compile time, 8 % 4 == 0), filled two k-steps ahead
+        bf16x8 bq[4][RN];
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            bq[0][j] = wload(0, 0, j);
+            bq[1][j] = wload(0, 1, j);
+        }
         __syncthreads();
-
-        bf16x8 bnext[RN];
 #pragma unroll
-        for (int j = 0; j < RN; j++) bnext[j] = *wptr(0, slice * 8, j);
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int j = 0; j < RN; j++) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Software pipeline over the 72 k-steps: the activation fragment of row tile rt for step s+1 is
+        // loaded into the register that the MFMAs of step s have just consumed, so every ds_read has a
+        // whole step to land; the weight fragments of step s+2 are issued at the top of step s.
+        int abase[RT];
+        tap_bases_rc<NB, RT, TAPS>(0, lr, q, ROWS, ZROW, abase);
+        bf16x8 av[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
         for (int tap = 0; tap < TAPS; tap++) {
-            const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
-            int abase[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                const int y = (yx[rt] & 0xff) + dy, x = (yx[rt] >> 8) + dx;
-                const bool ok = y >= 0 && y < NB && x >= 0 && x < NB;
-                const int sr = ok ? rt * 16 + lr + dy * NB + dx : ZROW;
-                abase[rt] = sr * LDS_STRIDE + q * 16;
-            }
 #pragma unroll
             for (int kc = 0; kc < 8; kc++) {
-                if (kc < kcs) {
+                if constexpr ((ABL & 2) == 0) {
+                    if (kc + 2 < 8) {
+#pragma unroll
+                        for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(tap, kc + 2, j);
+                    } else if (tap + 1 < TAPS) {
+#pragma unroll
+                        for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(tap + 1, kc + 2 - 8, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the issue point: hipcc otherwise sinks the loads to their use
+                }
+                if (kc == 7) tap_bases_rc<NB, RT, TAPS>(tap + 1 < TAPS ? tap + 1 : tap, lr, q, ROWS, ZROW, abase);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++)
+                        acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kc & 3][j], av[rt], acc[rt][j], 0, 0, 0);
+                    if constexpr ((ABL & 1) == 0) {
+                        if (kc < 7) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + (kc + 1) * 64);
+                        else av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+                    }
+                }
+            }
+        }
+    } else {
+        int yx[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            const int r = rt * 16 + lr, px = r % NN;
+            yx[rt] = r < ROWS ? ((px / NB) | ((px % NB) << 8)) : 0x7f7f;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int j = 0; j < RN; j++) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nslices = (a.cin_pad + 255) / 256;
+        for (int slice = 0; slice < nslices; slice++) {
+            const int cs = min(256, a.cin_pad - slice * 256);
+            const int kcs = cs / 32, cpr = cs / 8;
+            __syncthreads();
+            if constexpr (FROM_STATE) {
+                // game_repr fused into the tile loader: one thread per (board, square)
+                if (tid < LROWS) {
+                    const int row = tid;
+                    const bool ok = row < valid_rows;
+                    const tz_state* s = nullptr;
+                    int px = 0, fd = 0;
+                    if (ok) {
+                        const int pos = pos0 + row / NN;
+                        px = row % NN;
+                        s = a.states + (a.game_index ? a.game_index[pos] : pos);
+                        fd = state_flat_diff<NB>(s);
+                    }
+                    for (int c8 = 0; c8 < cpr; c8++) {
+                        bf16x8 v;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int c = c8 * 8 + k;
+                            v[k] = (__bf16)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
+                        }
+                        *reinterpret_cast<bf16x8*>(lds + row * LDS_STRIDE + c8 * 16) = v;
+                    }
+                }
+            } else {
+                const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+                for (int id = tid; id < LROWS * cpr; id += 512) {
+                    const int row = id / cpr, ci = id % cpr;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (row < valid_rows)
+                        v = *reinterpret_cast<const uint4*>(in + (m0 + row) * a.cin_pad + slice * 256 + ci * 8);
+                    *reinterpret_cast<uint4*>(lds + row * LDS_STRIDE + ci * 16) = v;
+                }
+            }
+            __syncthreads();
+            bf16x8 bnext[RN];
+#pragma unroll
+            for (int j = 0; j < RN; j++) bnext[j] = wload(0, slice * 8, j);
+            for (int tap = 0; tap < TAPS; tap++) {
+                int abase[RT];
+                tap_bases<NB, RT, TAPS>(yx, tap, lr, q, ZROW, abase);
+                for (int kc = 0; kc < kcs; kc++) {
                     bf16x8 bcur[RN];
 #pragma unroll
                     for (int j = 0; j < RN; j++) bcur[j] = bnext[j];
                     if (kc + 1 < kcs) {
 #pragma unroll
-                        for (int j = 0; j < RN; j++) bnext[j] = *wptr(tap, slice * 8 + kc + 1, j);
+                        for (int j = 0; j < RN; j++) bnext[j] = wload(tap, slice * 8 + kc + 1, j);
                     } else if (tap + 1 < TAPS) {
 #pragma unroll
-                        for (int j = 0; j < RN; j++) bnext[j] = *wptr(tap + 1, slice * 8, j);
+                        for (int j = 0; j < RN; j++) bnext[j] = wload(tap + 1, slice * 8, j);
                     }
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
@@ -637,11 +727,11 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
     return TZ_OK;
 }
 
-template <int NB, int RN, int TAPS, bool FROM_STATE>
+template <int NB, int RN, int TAPS, bool FROM_STATE, bool SINGLE = false>
 int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 1;
     const size_t smem = (size_t)LROWS * LDS_STRIDE;
-    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE>;
+    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, 0, SINGLE>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -683,8 +773,8 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
 #define TZ_CONV_CASE(NBV)                                                                   \
     case NBV:                                                                               \
         if (from_state) return launch_conv<NBV, 2, 9, true>(a, max_positions, by, st);      \
-        if (rn2) return launch_conv<NBV, 2, 9, false>(a, max_positions, by, st);            \
-        return launch_conv<NBV, 1, 9, false>(a, max_positions, by, st);
+        if (rn2) return launch_conv<NBV, 2, 9, false, true>(a, max_positions, by, st);      \
+        return launch_conv<NBV, 1, 9, false, true>(a, max_positions, by, st);
     switch (net->n) {
         TZ_CONV_CASE(3)
         TZ_CONV_CASE(4)
@@ -976,6 +1066,69 @@ int tz_net_load_weights(tz_net* net, const char* path) {
     fclose(f);
     if ((long)rd != sz) return tz_fail(TZ_EPARSE, "tz_net_load_weights: short read");
     return tz_net_load_weights_mem(net, buf.data(), buf.size());
+}
+
+// Diagnostic: time the residual-tower conv kernel (5x5, 256->256) on `positions` boards with an
+// ablation variant; returns average ms per launch over `iters` launches.
+int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, float* ms_out) {
+    if (!net || !net->loaded || net->n != 5 || net->precision != TZ_PREC_BF16 || net->res.empty())
+        return tz_fail(TZ_EINVAL, "tz_debug_conv_bench: needs a loaded 5x5 bf16 network");
+    TZ_HIP(hipSetDevice(net->device));
+    int rc = tz_net_ensure_batch(net, positions);
+    if (rc) return rc;
+    const ConvW& L = net->res[0];
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = net->act_a;
+    a.count_host = positions;
+    a.w = L.w_mfma;
+    a.bias = L.bias;
+    a.out = net->act_b;
+    a.cin_pad = L.cin_pad;
+    a.kc_total = L.cin_pad / 32;
+    a.ct_total = L.cout_pad / 16;
+    a.out_stride = FILTERS;
+    a.cin_real = L.cin;
+    a.relu = 1;
+    constexpr int P = ppt_for(5), RT = (P * 25 + 15) / 16, LROWS = RT * 16 + 1;
+    const size_t smem = (size_t)LROWS * LDS_STRIDE;
+    dim3 grid((positions + P - 1) / P, 1);
+    TZ_HIP(hipMemsetAsync(net->act_a, 0x3c, (size_t)positions * 25 * FILTERS * 2, net->stream));
+    hipEvent_t e0, e1;
+    TZ_HIP(hipEventCreate(&e0));
+    TZ_HIP(hipEventCreate(&e1));
+#define TZ_BENCH_VARIANT(V)                                                                                       \
+    case V: {                                                                                                     \
+        auto kern = conv_mfma_kernel<5, P, 2, 9, false, V, true>;                                                       \
+        TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);              \
+        TZ_HIP(hipEventRecord(e0, net->stream));                                                                  \
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);          \
+        TZ_HIP(hipEventRecord(e1, net->stream));                                                                  \
+    } break;
+    switch (variant) {
+        TZ_BENCH_VARIANT(0)
+        TZ_BENCH_VARIANT(1)
+        TZ_BENCH_VARIANT(2)
+        TZ_BENCH_VARIANT(3)
+        case 4: {  // one tap only: fixed per-workgroup cost (tile load, epilogue, launch) + 1/9 of the loop
+            auto kern = conv_mfma_kernel<5, P, 2, 1, false, 0, true>;
+            TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);
+            TZ_HIP(hipEventRecord(e0, net->stream));
+            for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);
+            TZ_HIP(hipEventRecord(e1, net->stream));
+        } break;
+        default: return tz_fail(TZ_EINVAL, "tz_debug_conv_bench: unknown variant");
+    }
+#undef TZ_BENCH_VARIANT
+    TZ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return TZ_OK;
 }
 
 int tz_net_destroy(tz_net* net) {
