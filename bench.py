@@ -172,7 +172,7 @@ def main():
             "targets_gathered": gathered,
         }
         if not args.no_profile and prof["conv_launches"]:
-            per_launch_positions = (evals1 - evals0) / max(1, prof["steps"])
+            per_launch_positions = (evals1 - evals0) / max(1.0, (sims1 - sims0) / args.games)
             flop_per_launch = CONV_FLOP_PER_POSITION * per_launch_positions
             avg_ms = prof["conv_ms"] / prof["conv_launches"]
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12

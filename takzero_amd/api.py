@@ -237,19 +237,25 @@ class BatchedMCTS:
         if not sample.any():
             return best
         ch = self.root_children()
+        amax = ch["visits"].shape[1]
+        valid = np.arange(amax)[None, :] < info["n_children"][:, None]
+        keys = eval_sort_keys(ch["eval_tag"], ch["eval_bits"])
+        best_key = np.where(valid, keys, np.inf).min(axis=1)
+        bi = np.where(valid, keys, np.inf).argmin(axis=1)
+        rows = np.arange(self.batch)
+        best_is_value = ch["eval_tag"][rows, bi] == EVAL_VALUE
+        drop = (ch["eval_bits"][rows, bi].view(np.float32) + np.float32(allowed_eval_drop)).astype(np.float64)
+        limit = np.where(best_is_value, drop, best_key)
+        w = np.where(valid & (ch["visits"] >= threshold) & (ch["eval_tag"] != EVAL_WIN) & (keys <= limit[:, None]),
+                     ch["visits"], 0).astype(np.float64)
+        tot = w.sum(axis=1)
+        pick = sample & (tot > 0)           # InsufficientNonZero -> best action
+        if not pick.any():
+            return best
+        u = rng.random(self.batch) * tot
+        idx = (np.cumsum(w, axis=1) > u[:, None]).argmax(axis=1)
         out = best.copy()
-        for g in np.nonzero(sample)[0]:
-            nc = int(info["n_children"][g])
-            tags, bits, vis = ch["eval_tag"][g, :nc], ch["eval_bits"][g, :nc], ch["visits"][g, :nc]
-            keys = [_eval_key(t, b) for t, b in zip(tags, bits)]
-            bi = min(range(nc), key=lambda i: keys[i])
-            limit = keys[bi]
-            if tags[bi] == EVAL_VALUE:
-                limit = _eval_key(EVAL_VALUE, np.float32(np.uint32(bits[bi]).view(np.float32) + np.float32(allowed_eval_drop)).view(np.uint32))
-            w = np.array([0 if (vis[i] < threshold or tags[i] == EVAL_WIN or keys[i] > limit) else int(vis[i])
-                          for i in range(nc)], dtype=np.float64)
-            if w.sum() > 0:
-                out[g] = ch["move_idx"][g, rng.choice(nc, p=w / w.sum())]
+        out[pick] = ch["move_idx"][rows[pick], idx[pick]]
         return out
 
     def improved_policy(self, visitations, amax=None):
@@ -290,14 +296,12 @@ class BatchedMCTS:
         return dict(conv_ms=cm.value, conv_launches=cl.value, tree_ms=tm.value, steps=st.value)
 
 
-def _eval_key(tag, bits):
-    """Total order of Eval (eval.rs:138-163) as a sortable tuple."""
-    tag, bits = int(tag), int(bits)
-    if tag == EVAL_LOSS:
-        return (0, bits, 0.0)
-    if tag == EVAL_WIN:
-        return (2, -bits, 0.0)
-    if tag == EVAL_DRAW:
-        return (1, -0.05, -bits)  # draws sit at CONTEMPT; slower draw first
-    v = float(np.uint32(bits).view(np.float32))
-    return (1, v, float("inf")) if v != -0.05 else (1, v, float("inf"))
+def eval_sort_keys(tags, bits):
+    """Total order of Eval (eval.rs:138-163) as float64 keys (vectorised): Loss(p) < Value / Draw < Win(p);
+    a faster loss is smaller, a faster win is larger, draws sit at CONTEMPT with slower draws first."""
+    tags = np.asarray(tags)
+    b = np.asarray(bits).astype(np.uint32)
+    v = b.view(np.float32).astype(np.float64)
+    p = b.astype(np.float64)
+    return np.select([tags == EVAL_LOSS, tags == EVAL_WIN, tags == EVAL_DRAW],
+                     [-1e9 + p, 1e9 - p, np.float64(np.float32(-0.05)) - p * 1e-12], default=v)

@@ -2,6 +2,7 @@
 // (tz_tree.hip) and the network (tz_nn.hip).  Reference: takzero/src/search/node/batched.rs:32-409.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -23,6 +24,12 @@ struct tz_search {
     tz_root_info* info_dev = nullptr;
     void* child_dev = nullptr;  // staging for root_children
     size_t child_cap = 0;
+    // one lock-step simulation captured as a HIP graph (index 0: from the roots, 1: from start nodes):
+    // ~60 launches per simulation would otherwise leave the GPU waiting for the host
+    hipGraphExec_t graph[2] = {nullptr, nullptr};
+    int warm[2] = {0, 0};
+    bool use_graph = true;
+    uint64_t sim_index = 0;
     // profiling
     bool profile = false;
     double tree_ms = 0.0;
@@ -78,11 +85,49 @@ int drain_profile(tz_search* s) {
     return TZ_OK;
 }
 
+int one_simulation_eager(tz_search* s, bool from_start, bool profile);
+
 // one lock-step simulation for every game (batched.rs:63-128)
 int one_simulation(tz_search* s, bool from_start) {
+    const int gi = from_start ? 1 : 0;
+    s->sim_index++;
+    // with profiling on, every 8th simulation runs eagerly with HIP events around its kernels
+    const bool sample = s->profile && (s->sim_index % 8 == 0);
+    if (!s->use_graph || sample || s->warm[gi] < 2) {
+        s->warm[gi]++;
+        return one_simulation_eager(s, from_start, sample);
+    }
+    if (!s->graph[gi]) {
+        hipGraph_t g = nullptr;
+        TZ_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = one_simulation_eager(s, from_start, false);
+        const hipError_t e = hipStreamEndCapture(s->stream, &g);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&s->graph[gi], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+    }
+    TZ_HIP(hipGraphLaunch(s->graph[gi], s->stream));
+    return TZ_OK;
+}
+
+int one_simulation_eager(tz_search* s, bool from_start, bool profile) {
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    if (s->profile) {
+    const bool saved_net_profile = s->net ? s->net->profile : false;
+    if (s->net) s->net->profile = profile;
+    struct Restore {
+        tz_search* s;
+        bool v;
+        ~Restore() {
+            if (s->net) s->net->profile = v;
+        }
+    } restore{s, saved_net_profile};
+    if (profile) {
         TZ_HIP(hipEventCreate(&e0));
         TZ_HIP(hipEventCreate(&e1));
         TZ_HIP(hipEventCreate(&e2));
@@ -91,15 +136,15 @@ int one_simulation(tz_search* s, bool from_start) {
     }
     if ((rc = tz_tree_descend(s->d, from_start, s->stream))) return rc;
     if ((rc = tz_tree_compact_leaves(s->d, s->stream))) return rc;
-    if (s->profile) TZ_HIP(hipEventRecord(e1, s->stream));
+    if (profile) TZ_HIP(hipEventRecord(e1, s->stream));
     NetOut out{nullptr, 0, nullptr, nullptr};
     if (s->d.agent_kind == TZ_AGENT_NET) {
         if ((rc = tz_net_forward_device(s->net, s->d.leaf_env, s->d.nn_game, s->d.nn_count, 0, s->d.batch, s->stream, &out)))
             return rc;
     }
-    if (s->profile) TZ_HIP(hipEventRecord(e2, s->stream));
+    if (profile) TZ_HIP(hipEventRecord(e2, s->stream));
     if ((rc = tz_tree_expand(s->d, out, s->stream))) return rc;
-    if (s->profile) {
+    if (profile) {
         TZ_HIP(hipEventRecord(e3, s->stream));
         s->tree_events.push_back({e0, e1});
         s->tree_events.push_back({e2, e3});
@@ -141,6 +186,7 @@ int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int ha
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return tz_fail(TZ_EDEVICE, "tz_search_create: no HIP device available (the HIP path has no CPU fallback)");
     tz_search* s = new tz_search();
+    s->use_graph = getenv("TZ_NO_GRAPH") == nullptr;
     s->net = agent_kind == TZ_AGENT_NET ? net : nullptr;
     s->device = s->net ? s->net->device : 0;
     TZ_HIP(hipSetDevice(s->device));
@@ -218,6 +264,8 @@ int tz_search_destroy(tz_search* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drain_profile(s);
+    for (int i = 0; i < 2; i++)
+        if (s->graph[i]) (void)hipGraphExecDestroy(s->graph[i]);
     SearchDev& d = s->d;
     void* ptrs[] = {d.t.eval_tag, d.t.eval_bits, d.t.visits, d.t.prob, d.t.logit, d.t.std_dev, d.t.child0, d.t.nchild,
                     d.t.action, d.bank, d.alloc, d.env, d.betas, d.traj, d.traj_len, d.start_node, d.leaf_kind,
@@ -573,7 +621,6 @@ int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_l
         if (s->net) {
             s->net->conv_ms = 0.0;
             s->net->conv_launches = 0;
-            s->net->profile = reset == 1;
         }
     }
     return TZ_OK;

@@ -31,7 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDS_STRIDE = 528;  // bytes per LDS row: 256 bf16 + 16 B pad (bank spread for ds_read_b128)
 constexpr int FILTERS = 256;
 
-__host__ __device__ constexpr int ppt_for(int nb) { return nb == 1 ? 208 : nb == 3 ? 16 : nb == 4 ? 12 : nb == 5 ? 8 : 4; }
+__host__ __device__ constexpr int ppt_for(int nb) { return nb == 1 ? 64 : nb == 3 ? 16 : nb == 4 ? 12 : nb == 5 ? 8 : 4; }
 
 __device__ __forceinline__ void default_reserves_d(int n, int& stones, int& caps) {
     stones = n == 3 ? 10 : n == 4 ? 15 : n == 5 ? 21 : 30;

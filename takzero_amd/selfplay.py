@@ -42,8 +42,9 @@ class SelfPlay:
         self.rng = np.random.default_rng([seed, shard])
         self.betas = np.zeros(mcts.batch, np.float32) if betas is None else np.asarray(betas, np.float32)
         self.collect = collect_targets
-        self.pending = [[] for _ in range(mcts.batch)]   # IncompleteTarget lists, selfplay/src/main.rs:230-236
-        self.replays = [[] for _ in range(mcts.batch)]
+        self.history = []          # per-move IncompleteTarget arrays (selfplay/src/main.rs:230-236)
+        self.history_base = 0      # move index of history[0]
+        self.game_start = np.zeros(mcts.batch, np.int64)  # move index at which each game's current episode began
         self.start_states = None
         self.moves_played = 0
         self.positions = 0
@@ -76,7 +77,8 @@ class SelfPlay:
         self.positions += B
         return targets, replays
 
-    # ---- target bookkeeping (host side, trivial cost: SURVEY.md §8a rows a22-a23)
+    # ---- target bookkeeping (host side: SURVEY.md §8a rows a22-a23).  One record per move for the whole
+    # shard (arrays), resolved per game only when that game ends.
     def _record(self, actions):
         m = self.mcts
         info = m.root_info()
@@ -90,32 +92,37 @@ class SelfPlay:
             visitations = (self.sims // lg // self.k) * (2 ** lg - 1)  # selfplay/src/main.rs:47-52
             pol = m.improved_policy(float(visitations), ch["visits"].shape[1])
         ube = m.ube_target(BETA)
-        for g in range(m.batch):
-            if info["eval_tag"][g] != api.EVAL_VALUE and info["eval_bits"][g] == 0:
-                continue  # terminal roots are not stepped (batched.rs:137)
-            nc = int(info["n_children"][g])
-            self.pending[g].append((states[g].copy(), ch["move_idx"][g, :nc].copy(), pol[g, :nc].copy(), float(ube[g])))
-            self.replays[g].append(int(actions[g]))
+        stepped = ~((info["eval_tag"] != api.EVAL_VALUE) & (info["eval_bits"] == 0))  # batched.rs:137
+        self.history.append(dict(states=states, moves=ch["move_idx"], pol=pol, ube=ube,
+                                 nchild=info["n_children"].copy(), stepped=stepped, actions=np.array(actions)))
 
     def _complete(self, term):
         targets, replays = [], []
-        new_states = None
-        for g in np.nonzero(term != api.TERMINAL_NONE)[0]:
+        done = np.nonzero(term != api.TERMINAL_NONE)[0]
+        new_states = self.mcts.get_positions() if len(done) else None
+        for g in done:
             # value walks back from the terminal Eval, negating at every step (selfplay/src/main.rs:294-326)
             tag = {api.TERMINAL_WIN: api.EVAL_WIN, api.TERMINAL_LOSS: api.EVAL_LOSS, api.TERMINAL_DRAW: api.EVAL_DRAW}[int(term[g])]
-            ply = 0
-            for state, moves, pol, ube in reversed(self.pending[g]):
+            ply, acts = 0, []
+            for h in reversed(self.history[self.game_start[g] - self.history_base:]):
+                if not h["stepped"][g]:
+                    continue
                 tag = {api.EVAL_WIN: api.EVAL_LOSS, api.EVAL_LOSS: api.EVAL_WIN, api.EVAL_DRAW: api.EVAL_DRAW}[tag]
                 ply += 1
-                value = float(api.eval_to_f32(tag, ply))
+                acts.append(int(h["actions"][g]))
+                state = h["states"][g]
                 if self.betas[g] == 0.0 or state["ply"] > WEIGHTED_RANDOM_PLIES:
-                    targets.append((state, moves, pol, value, ube))
-            replays.append((self.start_states[g].copy(), list(self.replays[g]), int(term[g])))
-            self.pending[g] = []
-            self.replays[g] = []
-            if new_states is None:
-                new_states = self.mcts.get_positions()
+                    k = int(h["nchild"][g])
+                    targets.append((state.copy(), h["moves"][g, :k].copy(), h["pol"][g, :k].copy(),
+                                    float(api.eval_to_f32(tag, ply)), float(h["ube"][g])))
+            replays.append((self.start_states[g].copy(), acts[::-1], int(term[g])))
+            self.game_start[g] = self.moves_played + 1
             self.start_states[g] = new_states[g]
+        # drop history no running game refers to any more
+        oldest = int(self.game_start.min())
+        while self.history_base < oldest and self.history:
+            self.history.pop(0)
+            self.history_base += 1
         return targets, replays
 
 
