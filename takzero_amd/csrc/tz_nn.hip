@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -28,8 +29,36 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LDS_STRIDE = 528;  // bytes per LDS row: 256 bf16 + 16 B pad (bank spread for ds_read_b128)
+// LDS activation tile, plane-major: [k-chunk kc (32 channels = 64 B)][row][64 B].  Inside a 64-B row segment the
+// four 16-B pieces q are rotated by 2*((row>>2)&1):  piece q of row r sits at (q + 2*((r>>2)&1)) & 3.  With the
+// 16x16x32 operand layout (lane = 16 rows x 4 pieces) and ds_read_b128's lane groups (each pairs 8 rows of piece q
+// with the other 8 rows of piece q^1) every group then touches 16 distinct 16-B slots, for any row shift; padding
+// alone cannot do that (it always leaves a 2-way conflict per group: 48 % of LDS cycles in the first version, PMC).
+// kc is an additive plane offset, so the reads of a k-step are one base register + immediates.
+// Rows RT*16 .. RT*16+7 of every plane are zero: an off-board tap reads zero row (source row & 7), i.e. the
+// same slot it would have used on the board.
+constexpr int LDS_ROWB = 64;
 constexpr int FILTERS = 256;
+__device__ __forceinline__ int lds_piece(int row, int q) { return ((q + 2 * ((row >> 2) & 1)) & 3) << 4; }
+// LAYOUT 1 = the plane-major image above.  LAYOUT 0 = row-major rows of 512 B + 16 B pad (the first version,
+// kept for in-process A/B: tz_debug_conv_bench).
+template <int LAYOUT>
+struct LdsImg {
+    static constexpr int ROW_PAD = 528;
+    __host__ __device__ static constexpr size_t bytes(int lrows) { return LAYOUT ? (size_t)lrows * LDS_ROWB * 8 : (size_t)lrows * ROW_PAD; }
+    // byte address of 16-B chunk `ci` (0..31) of row `row`
+    __device__ static __forceinline__ int store_addr(int row, int ci, int plane_bytes) {
+        return LAYOUT ? (ci >> 2) * plane_bytes + row * LDS_ROWB + lds_piece(row, ci & 3) : row * ROW_PAD + ci * 16;
+    }
+    // fragment base of source row v (or the zero row when !ok) for lane piece q; chunk kc adds kstep(kc)
+    __device__ static __forceinline__ int read_base(bool ok, int v, int q, int zrow) {
+        if (LAYOUT) {
+            const int sr = ok ? v : zrow + (v & 7);
+            return sr * LDS_ROWB + lds_piece(sr, q);
+        }
+        return (ok ? v : zrow) * ROW_PAD + q * 16;
+    }
+};
 
 __host__ __device__ constexpr int ppt_for(int nb) { return nb == 1 ? 64 : nb == 3 ? 16 : nb == 4 ? 12 : nb == 5 ? 8 : 4; }
 
@@ -103,19 +132,18 @@ struct ConvArgs {
 // 8 waves split the output channels (16*RN each) so each wave's weight fragments are private and
 // come straight from global memory; the activation tile is shared through LDS.
 // per-tap LDS byte offsets of a lane's 16-row fragments (row-shifted reads; off-board taps -> zero row)
-template <int NB, int RT, int TAPS>
+template <int NB, int RT, int TAPS, int LAYOUT>
 __device__ __forceinline__ void tap_bases(const int (&yx)[RT], int tap, int lr, int q, int zrow, int (&abase)[RT]) {
     const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
         const int y = (yx[rt] & 0xff) + dy, x = (yx[rt] >> 8) + dx;
         const bool ok = y >= 0 && y < NB && x >= 0 && x < NB;
-        const int sr = ok ? rt * 16 + lr + dy * NB + dx : zrow;
-        abase[rt] = sr * LDS_STRIDE + q * 16;
+        abase[rt] = LdsImg<LAYOUT>::read_base(ok, rt * 16 + lr + dy * NB + dx, q, zrow);
     }
 }
 
-template <int NB, int RT, int TAPS>
+template <int NB, int RT, int TAPS, int LAYOUT>
 __device__ __forceinline__ void tap_bases_rc(int tap, int lr, int q, int rows, int zrow, int (&abase)[RT]) {
     constexpr int NN = NB * NB;
     const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
@@ -124,17 +152,20 @@ __device__ __forceinline__ void tap_bases_rc(int tap, int lr, int q, int rows, i
         const int r = rt * 16 + lr, px = r % NN;
         const int y = px / NB + dy, x = px % NB + dx;
         const bool ok = r < rows && y >= 0 && y < NB && x >= 0 && x < NB;
-        const int sr = ok ? r + dy * NB + dx : zrow;
-        abase[rt] = sr * LDS_STRIDE + q * 16;
+        abase[rt] = LdsImg<LAYOUT>::read_base(ok, r + dy * NB + dx, q, zrow);
     }
 }
 
 // ABL (diagnostic builds only, tz_debug_conv_bench): 1 = no LDS fragment reads, 2 = no weight loads, 3 = neither.
 // SINGLE: the whole reduction is one 256-channel slice (tower and policy convs): unrolled tile loader,
 // weight fragments prefetched two k-steps ahead.
-template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false>
-__global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
-    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 1, ZROW = RT * 16;
+// NW = waves per workgroup; a workgroup covers NW*RN*16 output channels of P boards.
+template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false, int NW = 8, int LAYOUT = 1>
+__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  // 2 waves per SIMD: <= 256 registers
+    constexpr int NT = NW * 64;
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
+    constexpr int PLANE = LROWS * LDS_ROWB;
+    constexpr int KSTEP = LAYOUT ? PLANE : 64;  // byte distance between consecutive 32-channel chunks of a row
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int count = a.count_dev ? *a.count_dev : a.count_host;
     const int pos0 = blockIdx.x * P;
@@ -144,7 +175,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
     const int q = lane >> 4, lr = lane & 15;
     const int valid_rows = min(ROWS, (count - pos0) * NN);
     const size_t m0 = (size_t)pos0 * NN;
-    const int ct0 = (blockIdx.y * 8 + wave) * RN;
+    const int ct0 = (blockIdx.y * NW + wave) * RN;
     // fragment (tap, k-chunk, col tile) = 64 lanes x 16 B.  Buffer loads: descriptor + scalar fragment
     // offset in SGPRs, one VGPR (lane*16) for all of them -> no per-fragment 64-bit address registers.
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -161,18 +192,18 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
         static_assert(!FROM_STATE, "SINGLE is for bf16 activations");
         {   // every load of the tile is in flight before the first LDS store: one memory round trip
             const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
-            constexpr int NLOAD = (LROWS * 32 + 511) / 512;
+            constexpr int NLOAD = (LROWS * 32 + NT - 1) / NT;
             uint4 v[NLOAD];
 #pragma unroll
             for (int i = 0; i < NLOAD; i++) {
-                const int id = tid + i * 512, row = id >> 5, ci = id & 31;
+                const int id = tid + i * NT, row = id >> 5, ci = id & 31;
                 v[i] = make_uint4(0, 0, 0, 0);
                 if (row < valid_rows) v[i] = *reinterpret_cast<const uint4*>(in + (m0 + row) * 256 + ci * 8);
             }
 #pragma unroll
             for (int i = 0; i < NLOAD; i++) {
-                const int id = tid + i * 512, row = id >> 5, ci = id & 31;
-                if (row < LROWS) *reinterpret_cast<uint4*>(lds + row * LDS_STRIDE + ci * 16) = v[i];
+                const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+                if (row < LROWS) *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v[i];
             }
         }
         // weight ring: 4 slots, slot = kc & 3 (compile time, 8 % 4 == 0), filled two k-steps ahead
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
         // loaded into the register that the MFMAs of step s have just consumed, so every ds_read has a
         // whole step to land; the weight fragments of step s+2 are issued at the top of step s.
         int abase[RT];
-        tap_bases_rc<NB, RT, TAPS>(0, lr, q, ROWS, ZROW, abase);
+        tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr, q, ROWS, ZROW, abase);
         bf16x8 av[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
@@ -208,14 +239,27 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the issue point: hipcc otherwise sinks the loads to their use
                 }
-                if (kc == 7) tap_bases_rc<NB, RT, TAPS>(tap + 1 < TAPS ? tap + 1 : tap, lr, q, ROWS, ZROW, abase);
+                if (kc == 7) {
+                    // opaque copy: stops LICM from hoisting the per-row y/x decomposition out of the tap loop
+                    // (26 loop-invariant VGPRs that would be spilled)
+                    int lr_t = lr;
+                    asm volatile("" : "+v"(lr_t));
+                    tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
+                }
+                if (LAYOUT == 1 && kc == 4) {  // ds_read immediates reach 64 KB: rebase once per tap for planes 5..7
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        abase[rt] += 4 * PLANE;
+                        asm volatile("" : "+v"(abase[rt]));
+                    }
+                }
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
                     for (int j = 0; j < RN; j++)
                         acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kc & 3][j], av[rt], acc[rt][j], 0, 0, 0);
                     if constexpr ((ABL & 1) == 0) {
-                        if (kc < 7) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + (kc + 1) * 64);
+                        if (kc < 7) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + (kc + 1 - (LAYOUT == 1 && kc >= 4 ? 4 : 0)) * KSTEP);
                         else av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
                     }
                 }
@@ -239,8 +283,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
             __syncthreads();
             if constexpr (FROM_STATE) {
                 // game_repr fused into the tile loader: one thread per (board, square)
-                if (tid < LROWS) {
-                    const int row = tid;
+                for (int row = tid; row < LROWS; row += NT) {
                     const bool ok = row < valid_rows;
                     const tz_state* s = nullptr;
                     int px = 0, fd = 0;
@@ -257,17 +300,17 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
                             const int c = c8 * 8 + k;
                             v[k] = (__bf16)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
                         }
-                        *reinterpret_cast<bf16x8*>(lds + row * LDS_STRIDE + c8 * 16) = v;
+                        *reinterpret_cast<bf16x8*>(lds + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = v;
                     }
                 }
             } else {
                 const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
-                for (int id = tid; id < LROWS * cpr; id += 512) {
+                for (int id = tid; id < LROWS * cpr; id += NT) {
                     const int row = id / cpr, ci = id % cpr;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (row < valid_rows)
                         v = *reinterpret_cast<const uint4*>(in + (m0 + row) * a.cin_pad + slice * 256 + ci * 8);
-                    *reinterpret_cast<uint4*>(lds + row * LDS_STRIDE + ci * 16) = v;
+                    *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v;
                 }
             }
             __syncthreads();
@@ -276,7 +319,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
             for (int j = 0; j < RN; j++) bnext[j] = wload(0, slice * 8, j);
             for (int tap = 0; tap < TAPS; tap++) {
                 int abase[RT];
-                tap_bases<NB, RT, TAPS>(yx, tap, lr, q, ZROW, abase);
+                tap_bases<NB, RT, TAPS, LAYOUT>(yx, tap, lr, q, ZROW, abase);
                 for (int kc = 0; kc < kcs; kc++) {
                     bf16x8 bcur[RN];
 #pragma unroll
@@ -290,7 +333,7 @@ __global__ __launch_bounds__(512) void conv_mfma_kernel(ConvArgs a) {
                     }
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
-                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + kc * 64);
+                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + kc * KSTEP);
 #pragma unroll
                         for (int j = 0; j < RN; j++)
                             acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], av, acc[rt][j], 0, 0, 0);
@@ -727,21 +770,51 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
     return TZ_OK;
 }
 
-template <int NB, int RN, int TAPS, bool FROM_STATE, bool SINGLE = false>
+// Two tilings of the same kernel:
+//   cfg 0: 8 waves x 32 channels on P = ppt_for(N) boards   (1 workgroup per CU)
+//   cfg 1: 4 waves x 64 channels on P = ppt_small(N) boards (2 workgroups per CU: the tile load / epilogue of one
+//          overlaps the MFMA phase of the other, and every activation fragment feeds 4 MFMAs instead of 2)
+__host__ __device__ constexpr int ppt_small(int nb) { return nb == 1 ? 64 : nb == 3 ? 7 : nb == 4 ? 6 : nb == 5 ? 4 : 3; }
+
+int conv_cfg() {
+    static int cfg = -1;
+    if (cfg < 0) {
+        const char* e = getenv("TZ_CONV_CFG");
+        cfg = e ? atoi(e) : 0;  // cfg 1 measured slower on 5x5: its weight stream (2x the bytes per CU) saturates the L2->CU path
+    }
+    return cfg;
+}
+
+template <int NB, int P, int NW, int RN, int TAPS, bool FROM_STATE, bool SINGLE, int ABL = 0, int LAYOUT = 1>
 int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_t st) {
-    constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 1;
-    const size_t smem = (size_t)LROWS * LDS_STRIDE;
-    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, 0, SINGLE>;
+    constexpr int NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
+    const size_t smem = LdsImg<LAYOUT>::bytes(LROWS);
+    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, ABL, SINGLE, NW, LAYOUT>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((max_positions + P - 1) / P, n_blocks_y);
-    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("conv launch: ") + hipGetErrorString(e));
     return TZ_OK;
+}
+
+template <int NB>
+int conv_board(const ConvArgs& a, int cout_pad, bool from_state, int max_positions, hipStream_t st) {
+    constexpr int PA = ppt_for(NB), PB = ppt_small(NB);
+    const bool wide = cout_pad % 256 == 0;
+    const int by = wide ? cout_pad / 256 : cout_pad / 128;
+    if (conv_cfg() == 0) {
+        if (from_state) return launch_conv<NB, PA, 8, 2, 9, true, false>(a, max_positions, by, st);
+        if (wide) return launch_conv<NB, PA, 8, 2, 9, false, true>(a, max_positions, by, st);
+        return launch_conv<NB, PA, 8, 1, 9, false, true>(a, max_positions, by, st);
+    }
+    if (from_state) return launch_conv<NB, PB, 4, 4, 9, true, false>(a, max_positions, by, st);
+    if (wide) return launch_conv<NB, PB, 4, 4, 9, false, true>(a, max_positions, by, st);
+    return launch_conv<NB, PB, 4, 2, 9, false, true>(a, max_positions, by, st);
 }
 
 // one bf16 layer.  in==nullptr -> first layer from packed states.
@@ -766,22 +839,13 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     a.relu = relu;
     a.out_f32 = out_f32;
     a.has_res = residual != nullptr;
-    const bool from_state = in == nullptr;
-    if (!board) return launch_conv<1, 2, 1, false>(a, max_positions, L.cout_pad / 256, st);
-    const bool rn2 = L.cout_pad % 256 == 0;
-    const int by = rn2 ? L.cout_pad / 256 : L.cout_pad / 128;
-#define TZ_CONV_CASE(NBV)                                                                   \
-    case NBV:                                                                               \
-        if (from_state) return launch_conv<NBV, 2, 9, true>(a, max_positions, by, st);      \
-        if (rn2) return launch_conv<NBV, 2, 9, false, true>(a, max_positions, by, st);      \
-        return launch_conv<NBV, 1, 9, false, true>(a, max_positions, by, st);
+    if (!board) return launch_conv<1, 64, 8, 2, 1, false, false>(a, max_positions, L.cout_pad / 256, st);
     switch (net->n) {
-        TZ_CONV_CASE(3)
-        TZ_CONV_CASE(4)
-        TZ_CONV_CASE(5)
-        TZ_CONV_CASE(6)
+        case 3: return conv_board<3>(a, L.cout_pad, in == nullptr, max_positions, st);
+        case 4: return conv_board<4>(a, L.cout_pad, in == nullptr, max_positions, st);
+        case 5: return conv_board<5>(a, L.cout_pad, in == nullptr, max_positions, st);
+        case 6: return conv_board<6>(a, L.cout_pad, in == nullptr, max_positions, st);
     }
-#undef TZ_CONV_CASE
     return tz_fail(TZ_EINVAL, "conv: unsupported board size");
 }
 
@@ -1090,38 +1154,48 @@ int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, floa
     a.out_stride = FILTERS;
     a.cin_real = L.cin;
     a.relu = 1;
-    constexpr int P = ppt_for(5), RT = (P * 25 + 15) / 16, LROWS = RT * 16 + 1;
-    const size_t smem = (size_t)LROWS * LDS_STRIDE;
-    dim3 grid((positions + P - 1) / P, 1);
-    TZ_HIP(hipMemsetAsync(net->act_a, 0x3c, (size_t)positions * 25 * FILTERS * 2, net->stream));
+    {   // pseudo-random bf16 activations in [-1,1): zero or constant operands flatter the clock (DVFS)
+        std::vector<uint16_t> h((size_t)positions * 25 * FILTERS);
+        uint32_t x = 12345u;
+        for (auto& v : h) {
+            x = x * 1664525u + 1013904223u;
+            v = f2bf(((int)(x >> 8) % 20001 - 10000) * 1e-4f);
+        }
+        TZ_HIP(hipMemcpy(net->act_a, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        TZ_HIP(hipMemcpy(net->act_c, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
+    a.residual = net->act_c;
+    a.has_res = 1;
     hipEvent_t e0, e1;
     TZ_HIP(hipEventCreate(&e0));
     TZ_HIP(hipEventCreate(&e1));
-#define TZ_BENCH_VARIANT(V)                                                                                       \
-    case V: {                                                                                                     \
-        auto kern = conv_mfma_kernel<5, P, 2, 9, false, V, true>;                                                       \
-        TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);              \
-        TZ_HIP(hipEventRecord(e0, net->stream));                                                                  \
-        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);          \
-        TZ_HIP(hipEventRecord(e1, net->stream));                                                                  \
-    } break;
-    switch (variant) {
-        TZ_BENCH_VARIANT(0)
-        TZ_BENCH_VARIANT(1)
-        TZ_BENCH_VARIANT(2)
-        TZ_BENCH_VARIANT(3)
-        case 4: {  // one tap only: fixed per-workgroup cost (tile load, epilogue, launch) + 1/9 of the loop
-            auto kern = conv_mfma_kernel<5, P, 2, 1, false, 0, true>;
-            TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);
-            TZ_HIP(hipEventRecord(e0, net->stream));
-            for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, dim3(512), smem, net->stream, a);
-            TZ_HIP(hipEventRecord(e1, net->stream));
-        } break;
-        default: return tz_fail(TZ_EINVAL, "tz_debug_conv_bench: unknown variant");
-    }
-#undef TZ_BENCH_VARIANT
+    // variant = cfg * 10 + ablation (0 shipped, 1 no LDS reads, 2 no weight loads, 3 neither, 4 one tap only)
+    auto run = [&](int n) -> int {
+        int rc = TZ_OK;
+        for (int i = 0; i < n && !rc; i++) {
+            switch (variant) {
+                case 0: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 0>(a, positions, 1, net->stream); break;
+                case 1: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 1>(a, positions, 1, net->stream); break;
+                case 2: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 2>(a, positions, 1, net->stream); break;
+                case 3: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 3>(a, positions, 1, net->stream); break;
+                case 4: rc = launch_conv<5, ppt_for(5), 8, 2, 1, false, true, 0>(a, positions, 1, net->stream); break;
+                case 20: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 0, 0>(a, positions, 1, net->stream); break;
+                case 21: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 1, 0>(a, positions, 1, net->stream); break;
+                case 23: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 3, 0>(a, positions, 1, net->stream); break;
+                case 10: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 0>(a, positions, 1, net->stream); break;
+                case 11: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 1>(a, positions, 1, net->stream); break;
+                case 12: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 2>(a, positions, 1, net->stream); break;
+                case 13: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 3>(a, positions, 1, net->stream); break;
+                case 14: rc = launch_conv<5, ppt_small(5), 4, 4, 1, false, true, 0>(a, positions, 1, net->stream); break;
+                default: rc = tz_fail(TZ_EINVAL, "tz_debug_conv_bench: unknown variant");
+            }
+        }
+        return rc;
+    };
+    if ((rc = run(3))) return rc;
+    TZ_HIP(hipEventRecord(e0, net->stream));
+    if ((rc = run(iters))) return rc;
+    TZ_HIP(hipEventRecord(e1, net->stream));
     TZ_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     TZ_HIP(hipEventElapsedTime(&ms, e0, e1));
