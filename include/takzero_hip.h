@@ -193,6 +193,14 @@ int tz_search_step(tz_search* s, const uint16_t* actions);
  * (opening_choice as above) and a fresh tree; terminal_out[g] = TZ_TERMINAL_* of the game
  * that ended, TZ_TERMINAL_NONE otherwise. */
 int tz_search_restart_terminal(tz_search* s, const int32_t* opening_choice, int8_t* terminal_out);
+/* Details of the games that ended in the last tz_search_restart_terminal call: reason_out[g] = 1 road,
+ * 2 flat count, 3 reversible-plies draw (0 if the game did not end); winner_out[g] = 0 white, 1 black, 2 draw.
+ * Needed to write the PTN result of a Replay line (target.rs:215-232). */
+int tz_search_terminal_details(tz_search* s, int8_t* reason_out, uint8_t* winner_out);
+/* Validated move application without search (Replay::from_str / Replay::states, target.rs:205-212,248-268):
+ * actions[g] (0xFFFF = none) is applied to game g iff it is legal there; ok_out[g] = 1 applied, 0 illegal or
+ * none, -1 position already terminal.  Trees are reset. */
+int tz_search_play_moves(tz_search* s, const uint16_t* actions, int8_t* ok_out);
 /* BatchedMCTS::gumbel_sequential_halving with caller-supplied Gumbel(0,1) samples
  * (batched.rs:207-409): gumbel[batch][amax]; selected_out[batch] move indices. */
 int tz_search_gumbel_sh(tz_search* s, const float* betas, int sampled_actions, int search_budget,

@@ -29,7 +29,7 @@ SYMBOLS = [
     "tz_search_new_openings", "tz_search_simulate", "tz_search_apply_noise", "tz_search_root_info",
     "tz_search_root_children", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
     "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync",
-    "tz_search_profile", "tz_device_math", "tz_debug_conv_bench",
+    "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_search_terminal_details", "tz_search_play_moves",
 ]
 
 _lib = None
@@ -81,6 +81,8 @@ def load():
     lib.tz_search_sync.argtypes = [vp]
     lib.tz_search_profile.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64)]
+    lib.tz_search_terminal_details.argtypes = [vp, vp, vp]
+    lib.tz_search_play_moves.argtypes = [vp, vp, vp]
     lib.tz_device_math.argtypes = [ci, vp, vp, vp, ci]
     lib.tz_debug_conv_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     _lib = lib

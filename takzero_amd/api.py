@@ -282,6 +282,18 @@ class BatchedMCTS:
         check(self.lib.tz_search_restart_terminal(self.h, c.ctypes.data, out.ctypes.data))
         return out
 
+    def terminal_details(self):
+        reason = np.zeros(self.batch, np.int8)
+        winner = np.zeros(self.batch, np.uint8)
+        check(self.lib.tz_search_terminal_details(self.h, reason.ctypes.data, winner.ctypes.data))
+        return reason, winner
+
+    def play_moves(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.uint16)
+        ok = np.zeros(self.batch, np.int8)
+        check(self.lib.tz_search_play_moves(self.h, a.ctypes.data, ok.ctypes.data))
+        return ok
+
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()
         check(self.lib.tz_search_counters(self.h, C.byref(a), C.byref(b)))

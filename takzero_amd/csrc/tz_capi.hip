@@ -231,6 +231,8 @@ int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int ha
     rc |= dev_alloc(&d.bfs_src, (size_t)batch * d.cap);
     rc |= dev_alloc(&d.counters, 2);
     rc |= dev_alloc(&d.error_flag, 1);
+    rc |= dev_alloc(&d.term_reason, batch);
+    rc |= dev_alloc(&d.term_winner, batch);
     rc |= dev_alloc(&s->act_dev, batch);
     rc |= dev_alloc(&s->i32_dev, batch);
     rc |= dev_alloc(&s->i8_dev, batch);
@@ -270,6 +272,7 @@ int tz_search_destroy(tz_search* s) {
     void* ptrs[] = {d.t.eval_tag, d.t.eval_bits, d.t.visits, d.t.prob, d.t.logit, d.t.std_dev, d.t.child0, d.t.nchild,
                     d.t.action, d.bank, d.alloc, d.env, d.betas, d.traj, d.traj_len, d.start_node, d.leaf_kind,
                     d.leaf_nact, d.leaf_act, d.leaf_env, d.nn_game, d.nn_count, d.bfs_src, d.counters, d.error_flag,
+                    d.term_reason, d.term_winner,
                     s->noise_dev, s->act_dev, s->i32_dev, s->i8_dev, s->info_dev, s->child_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -517,6 +520,26 @@ int tz_search_restart_terminal(tz_search* s, const int32_t* opening_choice, int8
     int rc = tz_tree_restart(s->d, s->i32_dev, s->i8_dev, false, true, s->stream);
     if (rc) return rc;
     TZ_HIP(hipMemcpyAsync(terminal_out, s->i8_dev, s->d.batch, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipStreamSynchronize(s->stream));
+    return TZ_OK;
+}
+
+int tz_search_terminal_details(tz_search* s, int8_t* reason_out, uint8_t* winner_out) {
+    if (!s) return tz_fail(TZ_EINVAL, "tz_search_terminal_details: null argument");
+    TZ_HIP(hipSetDevice(s->device));
+    if (reason_out) TZ_HIP(hipMemcpyAsync(reason_out, s->d.term_reason, s->d.batch, hipMemcpyDeviceToHost, s->stream));
+    if (winner_out) TZ_HIP(hipMemcpyAsync(winner_out, s->d.term_winner, s->d.batch, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipStreamSynchronize(s->stream));
+    return TZ_OK;
+}
+
+int tz_search_play_moves(tz_search* s, const uint16_t* actions, int8_t* ok_out) {
+    if (!s || !actions || !ok_out) return tz_fail(TZ_EINVAL, "tz_search_play_moves: null argument");
+    TZ_HIP(hipSetDevice(s->device));
+    TZ_HIP(hipMemcpyAsync(s->act_dev, actions, s->d.batch * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+    int rc = tz_tree_play_moves(s->d, s->act_dev, s->i8_dev, s->stream);
+    if (rc) return rc;
+    TZ_HIP(hipMemcpyAsync(ok_out, s->i8_dev, s->d.batch, hipMemcpyDeviceToHost, s->stream));
     TZ_HIP(hipStreamSynchronize(s->stream));
     return TZ_OK;
 }

@@ -57,6 +57,8 @@ struct SearchDev {
     uint32_t* bfs_src;    // [batch][cap] scratch for subtree compaction
     unsigned long long* counters;  // [0] simulations, [1] nn leaf evals
     int32_t* error_flag;  // [1] sticky: 1 node pool overflow, 2 depth overflow, 3 action overflow
+    int8_t* term_reason;  // [batch] reason of the last terminal seen by restart_kernel (0 none, 1 road, 2 flats, 3 reversible plies)
+    uint8_t* term_winner; // [batch] 0 white, 1 black, 2 draw
 };
 
 // network outputs consumed by the expand kernel (device pointers, indexed by nn slot)
@@ -82,3 +84,4 @@ int tz_tree_restart(const SearchDev& s, const int32_t* choice_dev, int8_t* termi
 int tz_tree_reset_games(const SearchDev& s, const int32_t* idx_dev, int count, hipStream_t st);
 int tz_tree_set_start_children(const SearchDev& s, const int32_t* child_index_dev, hipStream_t st);
 int tz_tree_gumbel_root_fixup(const SearchDev& s, hipStream_t st);
+int tz_tree_play_moves(const SearchDev& s, const uint16_t* actions_dev, int8_t* ok_dev, hipStream_t st);

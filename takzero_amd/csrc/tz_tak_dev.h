@@ -150,24 +150,29 @@ __device__ __forceinline__ BoardScan scan_board(const tz_state* e) {
 }
 
 // Environment::terminal (env.rs:47-59): TZ_TERMINAL_* from the side to move. Wave-uniform.
+// *reason (optional): 0 ongoing, 1 road, 2 flat count (board full / reserves empty), 3 reversible-plies draw.
 template <int N>
-__device__ int terminal(const tz_state* e) {
+__device__ int terminal(const tz_state* e, int* reason = nullptr) {
     const BoardScan s = scan_board<N>(e);
     const int to_move = e->to_move, mover = 1 - to_move;
-    int winner = -1;  // 0 white, 1 black, 2 draw
+    int winner = -1, why = 0;  // 0 white, 1 black, 2 draw
     if (e->ply > 0) {
         if (has_road<N>(s.road[mover])) winner = mover;
         else if (has_road<N>(s.road[to_move])) winner = to_move;
+        if (winner >= 0) why = 1;
     }
     if (winner < 0) {
         const bool depleted = (e->stones[0] == 0 && e->caps[0] == 0) || (e->stones[1] == 0 && e->caps[1] == 0);
         if (s.empty == 0 || depleted) {
             const int w = 2 * __popcll(s.flats[0]), b = 2 * __popcll(s.flats[1]) + e->half_komi;
             winner = w > b ? 0 : b > w ? 1 : 2;
+            why = 2;
         } else if (e->reversible_plies >= TZ_REVERSIBLE_PLIES_LIMIT) {
             winner = 2;
+            why = 3;
         }
     }
+    if (reason) *reason = why;
     if (winner < 0) return TZ_TERMINAL_NONE;
     if (winner == 2) return TZ_TERMINAL_DRAW;
     return winner == to_move ? TZ_TERMINAL_WIN : TZ_TERMINAL_LOSS;

@@ -672,13 +672,59 @@ __global__ __launch_bounds__(64) void restart_kernel(SearchDev s, const int32_t*
     __shared__ tz_state env;
     load_state(&env, &s.env[g]);
     __syncthreads();
-    const int t = force_all ? TZ_TERMINAL_NONE : terminal<N>(&env);
+    int why = 0;
+    const int t = force_all ? TZ_TERMINAL_NONE : terminal<N>(&env, &why);
     if (l != 0) return;
     if (terminal_out) terminal_out[g] = (int8_t)t;
+    s.term_reason[g] = (int8_t)why;
+    // winner colour: the terminal is from the side to move
+    s.term_winner[g] = (uint8_t)(t == TZ_TERMINAL_DRAW ? 2 : t == TZ_TERMINAL_WIN ? env.to_move : 1 - env.to_move);
     if (t == TZ_TERMINAL_NONE && !force_all) return;
     write_opening<N>(&s.env[g], s.half_komi, choice ? choice[g] : 0, with_moves != 0);
     write_default_node(s, slab_base(s, s.bank[g], g));
     s.alloc[g] = 1;
+}
+
+// Validated replay step (Replay::from_str re-validates every move, target.rs:248-268): applies actions[g] to
+// game g's position iff it is one of its legal moves; ok[g] = 1 applied, 0 illegal (position unchanged),
+// -1 position already terminal.  Trees are reset.  0xFFFF = no move for this game.
+template <int N>
+__global__ __launch_bounds__(64) void play_moves_kernel(SearchDev s, const uint16_t* actions, int8_t* ok) {
+    constexpr int NN = N * N;
+    const int g = blockIdx.x, l = lane_id();
+    __shared__ tz_state env;
+    __shared__ uint8_t reach[NN * 4];
+    __shared__ uint16_t acts[1024];
+    const int a = actions[g];
+    if (a == 0xFFFF) {
+        if (l == 0) ok[g] = 0;
+        return;
+    }
+    load_state(&env, &s.env[g]);
+    __syncthreads();
+    if (terminal<N>(&env) != TZ_TERMINAL_NONE) {
+        if (l == 0) ok[g] = -1;
+        return;
+    }
+    const int n = gen_moves<N>(&env, reach, acts, 1024);
+    bool hit = false;
+    for (int i = l; i < n && i < 1024; i += 64) hit = hit || acts[i] == a;
+    if (!__any(hit)) {
+        if (l == 0) ok[g] = 0;
+        return;
+    }
+    apply_move<N>(&env, a);
+    __syncthreads();
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&env);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s.env[g]);
+        for (int i = l; i < (int)(sizeof(tz_state) / 4); i += 64) dst[i] = src[i];
+    }
+    if (l == 0) {
+        ok[g] = 1;
+        write_default_node(s, slab_base(s, s.bank[g], g));
+        s.alloc[g] = 1;
+    }
 }
 
 __global__ void reset_games_kernel(SearchDev s, const int32_t* idx, int count) {
@@ -830,6 +876,11 @@ int tz_tree_restart(const SearchDev& s, const int32_t* choice_dev, int8_t* termi
                     bool with_opening_moves, hipStream_t st) {
     TZ_DISPATCH_N(s.n, (restart_kernel<NB><<<s.batch, 64, 0, st>>>(s, choice_dev, terminal_dev, force_all ? 1 : 0,
                                                                   with_opening_moves ? 1 : 0)));
+    TZ_LAUNCH_CHECK();
+    return TZ_OK;
+}
+int tz_tree_play_moves(const SearchDev& s, const uint16_t* actions_dev, int8_t* ok_dev, hipStream_t st) {
+    TZ_DISPATCH_N(s.n, (play_moves_kernel<NB><<<s.batch, 64, 0, st>>>(s, actions_dev, ok_dev)));
     TZ_LAUNCH_CHECK();
     return TZ_OK;
 }
