@@ -100,12 +100,18 @@ def main():
     import torch
 
     dist = None
+    backend = os.environ.get("TZ_BENCH_BACKEND", "nccl")   # "gloo" + TZ_BENCH_DEVICE=0: rehearsal of N ranks on one GPU
+    if "TZ_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["TZ_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     import takzero_amd.api as A
     from takzero_amd import selfplay as SP
     from takzero_amd import weights as W
@@ -114,7 +120,7 @@ def main():
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
     sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank)
-    dev = "cuda:%d" % local_rank
+    dev = "cuda:%d" % local_rank if backend == "nccl" else "cpu"
 
     def barrier():
         mcts.sync()

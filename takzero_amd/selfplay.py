@@ -8,7 +8,7 @@ noise, early-ply move sampling) is drawn here from a counter-keyed numpy generat
 run of the oracle can be fed the same values."""
 import numpy as np
 
-from . import api
+from . import api, formats
 
 NOISE_ALPHA = 0.05   # selfplay/src/main.rs:39
 NOISE_RATIO = 0.2    # selfplay/src/main.rs:40
@@ -53,7 +53,8 @@ class SelfPlay:
             self.start_states = mcts.get_positions()
 
     def play_move(self):
-        """One outer-loop iteration of selfplay::main.  Returns (finished_targets, finished_replays)."""
+        """One outer-loop iteration of selfplay::main.  Returns (finished_targets, finished_replays): targets are
+        (state, moves, policy, value, ube), replays are (start_state, moves, PTN result)."""
         m, B = self.mcts, self.mcts.batch
         if self.search == "puct":
             m.simulate(self.betas, 1)                       # selfplay/src/main.rs:128
@@ -100,6 +101,7 @@ class SelfPlay:
         targets, replays = [], []
         done = np.nonzero(term != api.TERMINAL_NONE)[0]
         new_states = self.mcts.get_positions() if len(done) else None
+        reason, winner = self.mcts.terminal_details() if len(done) else (None, None)
         for g in done:
             # value walks back from the terminal Eval, negating at every step (selfplay/src/main.rs:294-326)
             tag = {api.TERMINAL_WIN: api.EVAL_WIN, api.TERMINAL_LOSS: api.EVAL_LOSS, api.TERMINAL_DRAW: api.EVAL_DRAW}[int(term[g])]
@@ -115,7 +117,7 @@ class SelfPlay:
                     k = int(h["nchild"][g])
                     targets.append((state.copy(), h["moves"][g, :k].copy(), h["pol"][g, :k].copy(),
                                     float(api.eval_to_f32(tag, ply)), float(h["ube"][g])))
-            replays.append((self.start_states[g].copy(), acts[::-1], int(term[g])))
+            replays.append((self.start_states[g].copy(), acts[::-1], formats.result_string(reason[g], winner[g])))
             self.game_start[g] = self.moves_played + 1
             self.start_states[g] = new_states[g]
         # drop history no running game refers to any more

@@ -55,13 +55,11 @@ def _selfplay_run(A, tmp_path, n=4, B=48, sims=12, moves=70, search="puct"):
     with open(tpath, "w") as tf, open(rpath, "w") as rf:
         for _ in range(moves):
             targets, replays = sp.play_move()
-            reason, winner = mcts.terminal_details()
             for st, mv, pol, value, ube in targets:
                 tf.write(F.format_target(n, st, mv, pol, value, ube))
                 nt += 1
-            for start, acts, term in replays:
-                # which game ended is not part of the tuple: recover the result from any ended game with this terminal
-                rf.write(F.format_replay(n, start, acts, None))
+            for start, acts, result in replays:
+                rf.write(F.format_replay(n, start, acts, result))
                 nr += 1
     return net, mcts, sp, tpath, rpath, nt, nr
 
@@ -93,6 +91,9 @@ def test_selfplay_writes_parseable_files_and_replays_revalidate(oracle, tmp_path
             assert oracle.tzo_terminal(C.byref(s)) == -1
             s = O.play(oracle, s, int(m))
         assert oracle.tzo_terminal(C.byref(s)) != -1
+        res = oracle.tzo_result(C.byref(s))  # 1 white, 2 black, 3 draw
+        tag = line.split()[-1]
+        assert tag in {1: ("R-0", "F-0"), 2: ("0-R", "0-F"), 3: ("1/2-1/2",)}[res], (tag, res)
         total_moves += len(moves)
     assert added == total_moves == len(buf.positions)
     assert buf.read_new(str(rpath)) == 0  # incremental tail: nothing new
@@ -132,7 +133,9 @@ def test_reanalyze_iteration(oracle, tmp_path):
             assert list(O.possible_moves(oracle, ost)) == [int(m) for m in mv]  # child order = possible_moves order
             assert abs(float(pol.sum(dtype=np.float64)) - 1.0) < 1e-4 and -1.0 <= value <= 1.0
             line = F.format_target(n, st, mv, pol, value, ube)
-            assert F.parse_target(line, n, 4)[0].tobytes() == st.tobytes()
+            back = st.copy()
+            back["reversible_plies"] = 0  # not representable in TPS (target.rs:322-326)
+            assert F.parse_target(line, n, 4)[0].tobytes() == back.tobytes()
     # sharding: rank r of 2 sees every second replay line
     b0, b1 = RA.PositionBuffer(mcts, n, 4, 0, 2), RA.PositionBuffer(mcts, n, 4, 1, 2)
     full = RA.PositionBuffer(mcts, n, 4)
