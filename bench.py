@@ -31,7 +31,9 @@ sys.path.insert(0, ROOT)
 
 N_BOARD, HALF_KOMI, GAMES, SIMS = 5, 4, 4096, 400
 FLOP_PER_POSITION = 1.2071e9          # net5, SURVEY.md §8d
-CONV_FLOP_PER_POSITION = 2 * 25 * 256 * 2304   # one 3x3 256->256 conv on one 5x5 board (the dominant kernel)
+CONV_FLOP_PER_POSITION = 2 * 25 * 256 * 2304   # one 3x3 256->256 conv on one 5x5 board
+TOWER_LAYERS = 40                              # net5: 20 residual blocks x 2 convs, fused into one launch
+FUSED_TOWER = os.environ.get("TZ_TOWER", "1") != "0"   # dominant kernel: the fused tower (default) or one conv
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 
 
@@ -179,12 +181,13 @@ def main():
         }
         if not args.no_profile and prof["conv_launches"]:
             per_launch_positions = (evals1 - evals0) / max(1.0, (sims1 - sims0) / args.games)
-            flop_per_launch = CONV_FLOP_PER_POSITION * per_launch_positions
+            flop_per_launch = CONV_FLOP_PER_POSITION * per_launch_positions * (TOWER_LAYERS if FUSED_TOWER else 1)
             avg_ms = prof["conv_ms"] / prof["conv_launches"]
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                               "kernel": "conv_mfma_kernel<5,8,2,9,false> (3x3 256->256 residual-tower conv)",
+                               "kernel": ("tower_mfma_kernel<5,8> (20 residual blocks = 40 3x3 256->256 convs, one persistent launch)"
+                                          if FUSED_TOWER else "conv_mfma_kernel<5,8,2,9,false,0,true,8,1> (one 3x3 256->256 conv)"),
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),

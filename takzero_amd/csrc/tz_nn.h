@@ -19,6 +19,8 @@ struct tz_net {
     bool loaded = false, has_rnd = false, has_hash = false;
     ConvW conv_in, policy;
     std::vector<ConvW> res;  // 2 per block
+    uint16_t* tower_w = nullptr;  // all residual-tower layers back to back (fused tower kernel)
+    float* tower_bias = nullptr;  // [2*blocks][256]
     float* heads = nullptr;  // [value conv w 256, ube conv w 256, value lin nn, ube lin nn, bv, bu, lbv, lbu]
     ConvW rnd[2][3];         // [learning, target][input, hidden, final]
     float rnd_min = 0.0f, rnd_max = 1.0f;

@@ -376,6 +376,170 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
 }
 
 // ---------------------------------------------------------------------------------------------
+// The whole residual tower in ONE launch (residual.rs:13-63 x blocks).  A workgroup keeps its P boards'
+// activations in LDS across all 2*blocks convolutions: after a conv the accumulators are ReLU'd, packed to
+// bf16 and written back into the same LDS image as the next conv's input; the block input x is re-read from
+// LDS into the accumulators (acc = x + bias) before it is overwritten, so the residual add costs no global
+// traffic and no registers.  Only the tower's input tile is loaded and only its final output is stored:
+// the per-layer tile-load / epilogue phases of the one-launch-per-conv form (~25 % of its time, all CUs hitting
+// HBM at once) disappear, as do 2*blocks-1 launch boundaries.  K-loop identical to conv_mfma_kernel<SINGLE>.
+struct TowerArgs {
+    const uint16_t* in;
+    uint16_t* out;
+    const uint16_t* w;   // layers back to back, each [9][8][16][64 lanes][8] bf16
+    const float* bias;   // [layers][256]
+    const int32_t* count_dev;
+    int count_host;
+    int nlayers;         // 2 * blocks
+};
+
+template <int NB, int P>
+__global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
+    constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
+    constexpr int PLANE = LROWS * LDS_ROWB, KSTEP = PLANE;
+    constexpr int LAYER_FRAGS = TAPS * 8 * 16;  // 1-KB fragments per layer
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int count = a.count_dev ? *a.count_dev : a.count_host;
+    const int pos0 = blockIdx.x * P;
+    if (pos0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, lr = lane & 15;
+    const int valid_rows = min(ROWS, (count - pos0) * NN);
+    const size_t m0 = (size_t)pos0 * NN;
+    const int ct0 = wave * RN;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    const int lane16 = lane * 16;
+    auto wload = [&](int layer, int tap, int kc, int j) -> bf16x8 {
+        const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0);
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    {   // tower input tile: every load in flight before the first LDS store
+        constexpr int NLOAD = (LROWS * 32 + NT - 1) / NT;
+        uint4 v[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (row < valid_rows) v[i] = *reinterpret_cast<const uint4*>(a.in + (m0 + row) * 256 + ci * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+            if (row < LROWS) *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v[i];
+        }
+    }
+    // address of this lane's 4 output channels of pixel row (rt*16 + lr) in the LDS image: its wave's 32
+    // channels are plane `wave`; + rt * 1024
+    int obase[RN];
+#pragma unroll
+    for (int j = 0; j < RN; j++)
+        obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
+
+    f32x4 acc[RT][RN];
+    for (int layer = 0; layer < a.nlayers; layer++) {
+        if ((layer & 1) == 0) {  // first conv of a block starts from its bias; the second from x + bias (below)
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + layer * FILTERS + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
+            }
+        }
+        bf16x8 bq[4][RN];
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            bq[0][j] = wload(layer, 0, 0, j);
+            bq[1][j] = wload(layer, 0, 1, j);
+        }
+        __syncthreads();  // the LDS image of this layer's input is complete
+        int abase[RT];
+        {
+            int lr_t = lr;
+            asm volatile("" : "+v"(lr_t));
+            tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr_t, q, ROWS, ZROW, abase);
+        }
+        bf16x8 av[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+        for (int tap = 0; tap < TAPS; tap++) {
+#pragma unroll
+            for (int kc = 0; kc < 8; kc++) {
+                if (kc + 2 < 8) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap, kc + 2, j);
+                } else if (tap + 1 < TAPS) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap + 1, kc + 2 - 8, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc == 7) {
+                    int lr_t = lr;
+                    asm volatile("" : "+v"(lr_t));
+                    tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
+                }
+                if (kc == 4) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        abase[rt] += 4 * PLANE;
+                        asm volatile("" : "+v"(abase[rt]));
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++)
+                        acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kc & 3][j], av[rt], acc[rt][j], 0, 0, 0);
+                    if (kc < 7) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * KSTEP);
+                    else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+                }
+            }
+        }
+        // ---- layer epilogue: ReLU, pack to bf16
+        bf16x4 pk[RT][RN];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int j = 0; j < RN; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) pk[rt][j][k] = (__bf16)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+        if (layer + 1 == a.nlayers) {
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const int cbase = (ct0 + j) * 16 + q * 4;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const int r = rt * 16 + lr;
+                    if (r < valid_rows) *reinterpret_cast<bf16x4*>(a.out + (m0 + r) * FILTERS + cbase) = pk[rt][j];
+                }
+            }
+            break;
+        }
+        if ((layer & 1) == 0) {
+            // second conv of the block accumulates onto x + bias: x is this block's input, still in LDS
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (layer + 1) * FILTERS + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const bf16x4 xv = *reinterpret_cast<const bf16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading the old image
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int j = 0; j < RN; j++) *reinterpret_cast<bf16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = pk[rt][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 validation path: one thread per (row, output channel); weights [tap][cin][cout].
 template <int NB>
 __global__ void conv_f32_kernel(const float* in, const float* w, const float* bias, const float* residual, float* out,
@@ -689,6 +853,8 @@ int bn_fold(const TensorMap& m, const std::string& p, int c, std::vector<float>&
 struct NetWeights {  // everything tz_net_load_weights replaces, so a failed load changes nothing
     ConvW conv_in, policy;
     std::vector<ConvW> res;
+    uint16_t* tower_w = nullptr;
+    float* tower_bias = nullptr;
     float* heads = nullptr;
     ConvW rnd[2][3];
     float rnd_min = 0.f, rnd_max = 1.f;
@@ -700,6 +866,10 @@ void free_weights(NetWeights& w) {
     free_layer(&w.policy);
     for (auto& l : w.res) free_layer(&l);
     w.res.clear();
+    if (w.tower_w) (void)hipFree(w.tower_w);
+    if (w.tower_bias) (void)hipFree(w.tower_bias);
+    w.tower_w = nullptr;
+    w.tower_bias = nullptr;
     if (w.heads) (void)hipFree(w.heads);
     w.heads = nullptr;
     for (int a = 0; a < 2; a++)
@@ -723,6 +893,15 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
             if ((rc = bn_fold(m, p + ".batch_norm", FILTERS, scale, bias))) return rc;
             if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h]))) return rc;
         }
+    if (prec == TZ_PREC_BF16 && net->blocks > 0) {  // the fused tower kernel reads all layers from one buffer
+        const size_t layer_elems = (size_t)9 * 8 * 16 * 64 * 8, nl = W.res.size();
+        TZ_HIP(hipMalloc(&W.tower_w, nl * layer_elems * 2));
+        TZ_HIP(hipMalloc(&W.tower_bias, nl * FILTERS * sizeof(float)));
+        for (size_t l = 0; l < nl; l++) {
+            TZ_HIP(hipMemcpy(W.tower_w + l * layer_elems, W.res[l].w_mfma, layer_elems * 2, hipMemcpyDeviceToDevice));
+            TZ_HIP(hipMemcpy(W.tower_bias + l * FILTERS, W.res[l].bias, FILTERS * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+    }
     if ((rc = get_tensor(m, "policy.conv2d.weight", (size_t)net->pol_ch * FILTERS * 9, w))) return rc;
     if ((rc = get_tensor(m, "policy.conv2d.bias", net->pol_ch, bias))) return rc;
     if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy))) return rc;
@@ -849,6 +1028,50 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     return tz_fail(TZ_EINVAL, "conv: unsupported board size");
 }
 
+bool tower_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TZ_TOWER");
+        on = e ? atoi(e) : 1;
+    }
+    return on != 0;
+}
+
+template <int NB>
+int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
+    constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
+    const size_t smem = (size_t)LROWS * LDS_ROWB * 8;
+    auto kern = tower_mfma_kernel<NB, P>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((max_positions + P - 1) / P), dim3(512), smem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tower launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+int tower_bf16(tz_net* net, const void* in, void* out, const int32_t* count_dev, int count_host, int max_positions,
+               hipStream_t st) {
+    TowerArgs a;
+    a.in = reinterpret_cast<const uint16_t*>(in);
+    a.out = reinterpret_cast<uint16_t*>(out);
+    a.w = net->tower_w;
+    a.bias = net->tower_bias;
+    a.count_dev = count_dev;
+    a.count_host = count_host;
+    a.nlayers = 2 * net->blocks;
+    switch (net->n) {
+        case 3: return launch_tower<3>(a, max_positions, st);
+        case 4: return launch_tower<4>(a, max_positions, st);
+        case 5: return launch_tower<5>(a, max_positions, st);
+        case 6: return launch_tower<6>(a, max_positions, st);
+    }
+    return tz_fail(TZ_EINVAL, "tower: unsupported board size");
+}
+
 int conv_f32(tz_net* net, const ConvW& L, const float* in, int in_stride, const int32_t* count_dev, int count_host,
              int max_positions, const float* residual, float* out, int out_stride, bool relu, bool board,
              hipStream_t st) {
@@ -939,25 +1162,42 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         if ((rc = conv_bf16(net, net->conv_in, nullptr, states, gidx, count_dev, count_host, max_positions, nullptr, x, FILTERS,
                             true, false, true, st)))
             return rc;
-        for (int b = 0; b < net->blocks; b++) {
+        if (net->blocks > 0 && net->tower_w && tower_enabled()) {
+            // the residual tower as one persistent launch
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (net->profile) {
                 TZ_HIP(hipEventCreate(&e0));
                 TZ_HIP(hipEventCreate(&e1));
                 TZ_HIP(hipEventRecord(e0, st));
             }
-            if ((rc = conv_bf16(net, net->res[2 * b], x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr, t,
-                                FILTERS, true, false, true, st)))
-                return rc;
-            if ((rc = conv_bf16(net, net->res[2 * b + 1], t, nullptr, nullptr, count_dev, count_host, max_positions, x, y,
-                                FILTERS, true, false, true, st)))
-                return rc;
+            if ((rc = tower_bf16(net, x, y, count_dev, count_host, max_positions, st))) return rc;
             if (net->profile) {
                 TZ_HIP(hipEventRecord(e1, st));
                 net->conv_events.push_back({e0, e1});
-                net->conv_launches += 2;
+                net->conv_launches += 1;
             }
             std::swap(x, y);
+        } else {
+            for (int b = 0; b < net->blocks; b++) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (net->profile) {
+                    TZ_HIP(hipEventCreate(&e0));
+                    TZ_HIP(hipEventCreate(&e1));
+                    TZ_HIP(hipEventRecord(e0, st));
+                }
+                if ((rc = conv_bf16(net, net->res[2 * b], x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr, t,
+                                    FILTERS, true, false, true, st)))
+                    return rc;
+                if ((rc = conv_bf16(net, net->res[2 * b + 1], t, nullptr, nullptr, count_dev, count_host, max_positions, x, y,
+                                    FILTERS, true, false, true, st)))
+                    return rc;
+                if (net->profile) {
+                    TZ_HIP(hipEventRecord(e1, st));
+                    net->conv_events.push_back({e0, e1});
+                    net->conv_launches += 2;
+                }
+                std::swap(x, y);
+            }
         }
         if ((rc = conv_bf16(net, net->policy, x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
                             net->policy_out, net->pol_stride, false, true, true, st)))
@@ -1100,6 +1340,8 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     old.conv_in = net->conv_in;
     old.policy = net->policy;
     old.res = net->res;
+    old.tower_w = net->tower_w;
+    old.tower_bias = net->tower_bias;
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) old.rnd[a][b] = net->rnd[a][b];
@@ -1107,6 +1349,8 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     net->conv_in = W.conv_in;
     net->policy = W.policy;
     net->res = W.res;
+    net->tower_w = W.tower_w;
+    net->tower_bias = W.tower_bias;
     net->heads = W.heads;
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) net->rnd[a][b] = W.rnd[a][b];
@@ -1213,6 +1457,8 @@ int tz_net_destroy(tz_net* net) {
     old.conv_in = net->conv_in;
     old.policy = net->policy;
     old.res = net->res;
+    old.tower_w = net->tower_w;
+    old.tower_bias = net->tower_bias;
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) old.rnd[a][b] = net->rnd[a][b];
