@@ -498,14 +498,9 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 }
             }
         }
-        // ---- layer epilogue: ReLU, pack to bf16
-        bf16x4 pk[RT][RN];
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int j = 0; j < RN; j++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) pk[rt][j][k] = (__bf16)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+        // ---- layer epilogue.  A wave's 32 output channels are exactly one plane of the LDS image, and it is the
+        // only wave that reads that plane's residual: after one barrier (all K-loops done) each lane can
+        // replace its own 8 bytes in place - read x (for the residual), write ReLU(acc) - with no staging.
         if (layer + 1 == a.nlayers) {
 #pragma unroll
             for (int j = 0; j < RN; j++) {
@@ -513,29 +508,34 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
                     const int r = rt * 16 + lr;
-                    if (r < valid_rows) *reinterpret_cast<bf16x4*>(a.out + (m0 + r) * FILTERS + cbase) = pk[rt][j];
+                    bf16x4 pk;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pk[k] = (__bf16)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    if (r < valid_rows) *reinterpret_cast<bf16x4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
                 }
             }
             break;
         }
-        if ((layer & 1) == 0) {
-            // second conv of the block accumulates onto x + bias: x is this block's input, still in LDS
+        __syncthreads();  // every wave is done reading the old image
+        const bool to_second = (layer & 1) == 0;  // next conv is the block's second: it starts from x + bias
 #pragma unroll
-            for (int j = 0; j < RN; j++) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (layer + 1) * FILTERS + (ct0 + j) * 16 + q * 4);
+        for (int j = 0; j < RN; j++) {
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (to_second) b4 = *reinterpret_cast<const f32x4*>(a.bias + (layer + 1) * FILTERS + (ct0 + j) * 16 + q * 4);
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    const bf16x4 xv = *reinterpret_cast<const bf16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
+            for (int rt = 0; rt < RT; rt++) {
+                bf16x4* slot = reinterpret_cast<bf16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
+                bf16x4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; k++) pk[k] = (__bf16)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                if (to_second) {
+                    const bf16x4 xv = *slot;
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
                 }
+                *slot = pk;
             }
         }
-        __syncthreads();  // every wave is done reading the old image
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int j = 0; j < RN; j++) *reinterpret_cast<bf16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = pk[rt][j];
     }
 }
 
