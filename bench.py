@@ -184,8 +184,12 @@ def main():
             flop_per_launch = CONV_FLOP_PER_POSITION * per_launch_positions * (TOWER_LAYERS if FUSED_TOWER else 1)
             avg_ms = prof["conv_ms"] / prof["conv_launches"]
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+            traffic = None   # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/)
+            tpath = os.path.join(ROOT, "profiles", "tower_pmc_traffic.json")
+            if FUSED_TOWER and args.games == GAMES and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "kernel": ("tower_mfma_kernel<5,8> (20 residual blocks = 40 3x3 256->256 convs, one persistent launch)"
                                           if FUSED_TOWER else "conv_mfma_kernel<5,8,2,9,false,0,true,8,1> (one 3x3 256->256 conv)"),
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
