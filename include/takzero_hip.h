@@ -145,6 +145,12 @@ int tz_net_encode(tz_net* net, int batch, const tz_state* states, float* planes_
 int tz_net_forward_raw(tz_net* net, int batch, const tz_state* states, float* policy_out,
                        float* value_out, float* ube_out);
 
+/* SimHash nets (net4_simhash / net6_simhash): HashNetwork::get_indices / update_counts
+ * (net6_simhash.rs:202-243) and the bitvec.bin file that accompanies a model (net6_simhash.rs:152-190). */
+int tz_net_hash_indices(tz_net* net, int batch, const tz_state* states, uint32_t* indices_out, int update);
+int tz_net_load_bitset(tz_net* net, const char* path);
+int tz_net_save_bitset(tz_net* net, const char* path);
+
 /* ---------- BatchedMCTS (search/node/batched.rs:32-409) ---------- */
 /* BatchedMCTS::from_envs with default (empty-board) envs; node_capacity = node slots per game
  * (0 = default).  net may be NULL when agent_kind != TZ_AGENT_NET. */
@@ -207,6 +213,8 @@ int tz_search_gumbel_sh(tz_search* s, const float* betas, int sampled_actions, i
                         const float* gumbel, int amax, uint16_t* selected_out);
 /* counters since creation: simulations (incl. Known hits) and network-evaluated leaves */
 int tz_search_counters(tz_search* s, uint64_t* simulations, uint64_t* nn_leaf_evals);
+/* node slots in use in the fullest game's pool, and the per-game capacity */
+int tz_search_pool_usage(tz_search* s, uint32_t* max_used, uint32_t* capacity);
 int tz_search_sync(tz_search* s);
 /* time spent (ms, HIP events on the handle's stream) in the dominant conv kernel and its
  * launch count since the last reset; used by bench.py for the roofline line. */
@@ -219,6 +227,8 @@ int tz_device_math(int op, const float* a, const float* b, float* out, int n);
 /* Diagnostic: average ms per launch of the 5x5 residual-tower conv kernel on `positions` boards;
  * variant 0 = the shipped kernel, 1/2/3 = ablations (no LDS reads / no weight loads / neither). */
 int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, float* ms_out);
+/* Diagnostic: the same for the fused residual-tower kernel (variant = its OPT bitmask). */
+int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -24,12 +24,12 @@ assert STATE_DTYPE.itemsize == 376 and ROOT_INFO_DTYPE.itemsize == 28
 SYMBOLS = [
     "tz_last_error", "tz_version", "tz_device_count", "tz_state_from_tps", "tz_state_to_tps", "tz_move_to_ptn",
     "tz_move_from_ptn", "tz_policy_size", "tz_input_channels", "tz_net_create", "tz_net_load_weights",
-    "tz_net_load_weights_mem", "tz_net_destroy", "tz_net_eval", "tz_net_encode", "tz_net_forward_raw",
+    "tz_net_load_weights_mem", "tz_net_destroy", "tz_net_eval", "tz_net_encode", "tz_net_forward_raw", "tz_net_hash_indices", "tz_net_load_bitset", "tz_net_save_bitset",
     "tz_search_create", "tz_search_destroy", "tz_search_set_positions", "tz_search_get_positions",
     "tz_search_new_openings", "tz_search_simulate", "tz_search_apply_noise", "tz_search_root_info",
     "tz_search_root_children", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
-    "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync",
-    "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_search_terminal_details", "tz_search_play_moves",
+    "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync", "tz_search_pool_usage",
+    "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_search_terminal_details", "tz_search_play_moves",
 ]
 
 _lib = None
@@ -62,6 +62,9 @@ def load():
     lib.tz_net_eval.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp]
     lib.tz_net_encode.argtypes = [vp, ci, vp, vp]
     lib.tz_net_forward_raw.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.tz_net_hash_indices.argtypes = [vp, ci, vp, vp, ci]
+    lib.tz_net_load_bitset.argtypes = [vp, C.c_char_p]
+    lib.tz_net_save_bitset.argtypes = [vp, C.c_char_p]
     lib.tz_search_create.argtypes = [vp, ci, ci, ci, ci, ci, C.POINTER(vp)]
     lib.tz_search_destroy.argtypes = [vp]
     lib.tz_search_set_positions.argtypes = [vp, ci, vp, vp]
@@ -79,12 +82,14 @@ def load():
     lib.tz_search_gumbel_sh.argtypes = [vp, vp, ci, ci, vp, ci, vp]
     lib.tz_search_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.tz_search_sync.argtypes = [vp]
+    lib.tz_search_pool_usage.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.tz_search_profile.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64)]
     lib.tz_search_terminal_details.argtypes = [vp, vp, vp]
     lib.tz_search_play_moves.argtypes = [vp, vp, vp]
     lib.tz_device_math.argtypes = [ci, vp, vp, vp, ci]
     lib.tz_debug_conv_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
+    lib.tz_debug_tower_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 

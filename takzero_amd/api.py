@@ -128,6 +128,19 @@ class Net:
                                    logits.ctypes.data, value.ctypes.data, var.ctypes.data))
         return [logits[i, :cnt[i]].copy() for i in range(b)], value, var
 
+    def hash_indices(self, env_batch, update=False):
+        """HashNetwork::get_indices (and update_counts when update=True), net6_simhash.rs:202-243."""
+        st = _states(env_batch)
+        out = np.zeros(len(st), np.uint32)
+        check(self.lib.tz_net_hash_indices(self.h, len(st), st.ctypes.data, out.ctypes.data, 1 if update else 0))
+        return out
+
+    def load_bitset(self, path):
+        check(self.lib.tz_net_load_bitset(self.h, str(path).encode()))
+
+    def save_bitset(self, path):
+        check(self.lib.tz_net_save_bitset(self.h, str(path).encode()))
+
     def encode(self, env_batch):
         st = _states(env_batch)
         out = np.zeros((len(st), input_channels(self.n) * self.n * self.n), np.float32)
@@ -297,6 +310,11 @@ class BatchedMCTS:
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()
         check(self.lib.tz_search_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def pool_usage(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(self.lib.tz_search_pool_usage(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def sync(self):

@@ -621,6 +621,19 @@ int tz_search_counters(tz_search* s, uint64_t* simulations, uint64_t* nn_leaf_ev
     return TZ_OK;
 }
 
+int tz_search_pool_usage(tz_search* s, uint32_t* max_used, uint32_t* capacity) {
+    if (!s) return tz_fail(TZ_EINVAL, "tz_search_pool_usage: null argument");
+    TZ_HIP(hipSetDevice(s->device));
+    std::vector<uint32_t> h(s->d.batch);
+    TZ_HIP(hipMemcpyAsync(h.data(), s->d.alloc, h.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipStreamSynchronize(s->stream));
+    uint32_t m = 0;
+    for (uint32_t v : h) m = std::max(m, v);
+    if (max_used) *max_used = m;
+    if (capacity) *capacity = (uint32_t)s->d.cap;
+    return TZ_OK;
+}
+
 int tz_search_sync(tz_search* s) {
     if (!s) return tz_fail(TZ_EINVAL, "tz_search_sync: null argument");
     TZ_HIP(hipSetDevice(s->device));

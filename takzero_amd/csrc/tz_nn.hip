@@ -393,7 +393,9 @@ struct TowerArgs {
     int nlayers;         // 2 * blocks
 };
 
-template <int NB, int P>
+// OPT: bit 0 = fetch the next layer's first weight fragments during the last two k-steps (A/B switch for
+// tz_debug_tower_bench; shipped value in launch_tower)
+template <int NB, int P, int OPT = 0>
 __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
     constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
         obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
 
     f32x4 acc[RT][RN];
+    bf16x8 bq[4][RN];  // weight ring; slots 0/1 of the next layer are fetched during the last two k-steps of this one
     for (int layer = 0; layer < a.nlayers; layer++) {
         if ((layer & 1) == 0) {  // first conv of a block starts from its bias; the second from x + bias (below)
 #pragma unroll
@@ -449,13 +452,22 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
             }
         }
-        bf16x8 bq[4][RN];
+        if (layer == 0 || !(OPT & 1)) {
 #pragma unroll
-        for (int j = 0; j < RN; j++) {
-            bq[0][j] = wload(layer, 0, 0, j);
-            bq[1][j] = wload(layer, 0, 1, j);
+            for (int j = 0; j < RN; j++) {
+                bq[0][j] = wload(layer, 0, 0, j);
+                bq[1][j] = wload(layer, 0, 1, j);
+            }
         }
         __syncthreads();  // the LDS image of this layer's input is complete
+        // The two waves that share a SIMD (w and w+4) run the same program; delayed by part of a k-step, the
+        // VALU-only stretch at each tap boundary of one falls into the MFMA stretch of the other.
+        if constexpr (OPT & 2) {
+            if (wave >= 4) __builtin_amdgcn_s_sleep(4);
+        }
+        if constexpr (OPT & 4) {
+            if (wave >= 4) __builtin_amdgcn_s_sleep(10);
+        }
         int abase[RT];
         {
             int lr_t = lr;
@@ -474,6 +486,9 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 } else if (tap + 1 < TAPS) {
 #pragma unroll
                     for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap + 1, kc + 2 - 8, j);
+                } else if ((OPT & 1) && layer + 1 < a.nlayers) {  // next layer's first fragments ride under this layer's epilogue
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer + 1, 0, kc + 2 - 8, j);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kc == 7) {
@@ -686,6 +701,12 @@ __global__ __launch_bounds__(64) void simhash_kernel(const float* planes, const 
         local[pos] = seen ? 0.0f : 4.0f;
         if (index_out) index_out[pos] = index;
     }
+}
+
+// HashNetwork::update_counts (net6_simhash.rs:238-243): set the bit of every index
+__global__ void bitset_set_kernel(uint32_t* bitset, const uint32_t* index, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&bitset[index[i] >> 5], 1u << (index[i] & 31));
 }
 
 // logits of the legal actions: out[b][j] = policy[b][px(a)][ch(a)]  (net5.rs:239-267)
@@ -1037,11 +1058,11 @@ bool tower_enabled() {
     return on != 0;
 }
 
-template <int NB>
+template <int NB, int OPT = 0>
 int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8;
-    auto kern = tower_mfma_kernel<NB, P>;
+    auto kern = tower_mfma_kernel<NB, P, OPT>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1449,6 +1470,60 @@ int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, floa
     return TZ_OK;
 }
 
+// Diagnostic: average ms per launch of the fused 5x5 tower (the net's own weights) on `positions` boards of
+// pseudo-random activations; variant = OPT bitmask of tower_mfma_kernel.  For in-process A/B.
+int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, float* ms_out) {
+    if (!net || !net->loaded || net->n != 5 || net->precision != TZ_PREC_BF16 || !net->tower_w)
+        return tz_fail(TZ_EINVAL, "tz_debug_tower_bench: needs a loaded 5x5 bf16 network");
+    TZ_HIP(hipSetDevice(net->device));
+    int rc = tz_net_ensure_batch(net, positions);
+    if (rc) return rc;
+    {
+        std::vector<uint16_t> h((size_t)positions * 25 * FILTERS);
+        uint32_t x = 999u;
+        for (auto& v : h) {
+            x = x * 1664525u + 1013904223u;
+            v = (x >> 31) ? 0 : f2bf((float)((x >> 8) % 10001) * 1e-4f);  // post-ReLU-like: half zeros
+        }
+        TZ_HIP(hipMemcpy(net->act_a, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
+    TowerArgs a;
+    a.in = reinterpret_cast<const uint16_t*>(net->act_a);
+    a.out = reinterpret_cast<uint16_t*>(net->act_b);
+    a.w = net->tower_w;
+    a.bias = net->tower_bias;
+    a.count_dev = nullptr;
+    a.count_host = positions;
+    a.nlayers = 2 * net->blocks;
+    hipEvent_t e0, e1;
+    TZ_HIP(hipEventCreate(&e0));
+    TZ_HIP(hipEventCreate(&e1));
+    auto run = [&](int n) -> int {
+        int r = TZ_OK;
+        for (int i = 0; i < n && !r; i++) {
+            switch (variant) {
+                case 0: r = launch_tower<5, 0>(a, positions, net->stream); break;
+                case 1: r = launch_tower<5, 1>(a, positions, net->stream); break;
+                case 2: r = launch_tower<5, 2>(a, positions, net->stream); break;
+                case 4: r = launch_tower<5, 4>(a, positions, net->stream); break;
+                default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
+            }
+        }
+        return r;
+    };
+    if ((rc = run(2))) return rc;
+    TZ_HIP(hipEventRecord(e0, net->stream));
+    if ((rc = run(iters))) return rc;
+    TZ_HIP(hipEventRecord(e1, net->stream));
+    TZ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return TZ_OK;
+}
+
 int tz_net_destroy(tz_net* net) {
     if (!net) return TZ_OK;
     (void)hipSetDevice(net->device);
@@ -1561,6 +1636,84 @@ int tz_net_encode(tz_net* net, int batch, const tz_state* states, float* planes_
     if (dout) (void)hipFree(dout);
     if (rc) return rc;
     if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tz_net_encode: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+// HashNetwork::{get_indices, update_counts} and the bitvec.bin half of Network::load for the SimHash nets
+// (net6_simhash.rs:152-190,202-243).  indices_out may be NULL; update != 0 also marks the positions as seen.
+int tz_net_hash_indices(tz_net* net, int batch, const tz_state* states, uint32_t* indices_out, int update) {
+    if (!net || !states || batch <= 0) return tz_fail(TZ_EINVAL, "tz_net_hash_indices: bad argument");
+    if (!net->has_hash || !net->loaded) return tz_fail(TZ_ESTATE, "tz_net_hash_indices: not a loaded SimHash network");
+    tz_state* dstates = nullptr;
+    int rc = net_upload_states(net, batch, states, &dstates);
+    if (rc) return rc;
+    hipStream_t st = net->stream;
+    uint32_t* didx = nullptr;
+    hipError_t e = hipMalloc(&didx, batch * 4);
+    if (e == hipSuccess) {
+        rc = encode(net, dstates, nullptr, nullptr, batch, batch, st);
+        if (!rc) {
+            simhash_kernel<<<batch, 64, 0, st>>>(net->planes, net->simhash, net->bitset, nullptr, batch, net->nn, net->cin, net->aux, didx);
+            if (update) bitset_set_kernel<<<(batch + 255) / 256, 256, 0, st>>>(net->bitset, didx, batch);
+            if (indices_out) e = hipMemcpyAsync(indices_out, didx, batch * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
+    (void)hipFree(dstates);
+    if (didx) (void)hipFree(didx);
+    if (rc) return rc;
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tz_net_hash_indices: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+// bitvec.bin: the raw words of the reference's BitBox<usize, Lsb0> (2^32 bits = 512 MiB), net6_simhash.rs:152-190
+int tz_net_load_bitset(tz_net* net, const char* path) {
+    if (!net || !path) return tz_fail(TZ_EINVAL, "tz_net_load_bitset: null argument");
+    if (!net->has_hash) return tz_fail(TZ_ESTATE, "tz_net_load_bitset: not a SimHash network");
+    TZ_HIP(hipSetDevice(net->device));
+    FILE* f = fopen(path, "rb");
+    if (!f) return tz_fail(TZ_EPARSE, std::string("tz_net_load_bitset: cannot open ") + path);
+    const size_t total = (size_t)1 << 29, chunk = (size_t)1 << 26;
+    std::vector<unsigned char> buf(chunk);
+    uint32_t* staging = nullptr;   // a failed load leaves the old set active
+    if (hipMalloc(&staging, total) != hipSuccess) {
+        fclose(f);
+        return tz_fail(TZ_ENOMEM, "tz_net_load_bitset: cannot allocate the staging set");
+    }
+    size_t done = 0;
+    while (done < total) {
+        const size_t rd = fread(buf.data(), 1, chunk, f);
+        if (rd != chunk || hipMemcpy((unsigned char*)staging + done, buf.data(), chunk, hipMemcpyHostToDevice) != hipSuccess) break;
+        done += chunk;
+    }
+    fclose(f);
+    if (done != total) {
+        (void)hipFree(staging);
+        return tz_fail(TZ_EPARSE, "tz_net_load_bitset: file is not 2^32 bits");
+    }
+    TZ_HIP(hipStreamSynchronize(net->stream));
+    (void)hipFree(net->bitset);
+    net->bitset = staging;
+    return TZ_OK;
+}
+
+int tz_net_save_bitset(tz_net* net, const char* path) {
+    if (!net || !path) return tz_fail(TZ_EINVAL, "tz_net_save_bitset: null argument");
+    if (!net->has_hash) return tz_fail(TZ_ESTATE, "tz_net_save_bitset: not a SimHash network");
+    TZ_HIP(hipSetDevice(net->device));
+    TZ_HIP(hipStreamSynchronize(net->stream));
+    FILE* f = fopen(path, "wb");
+    if (!f) return tz_fail(TZ_EPARSE, std::string("tz_net_save_bitset: cannot open ") + path);
+    const size_t total = (size_t)1 << 29, chunk = (size_t)1 << 26;
+    std::vector<unsigned char> buf(chunk);
+    for (size_t done = 0; done < total; done += chunk) {
+        if (hipMemcpy(buf.data(), (unsigned char*)net->bitset + done, chunk, hipMemcpyDeviceToHost) != hipSuccess ||
+            fwrite(buf.data(), 1, chunk, f) != chunk) {
+            fclose(f);
+            return tz_fail(TZ_EDEVICE, "tz_net_save_bitset: write failed");
+        }
+    }
+    fclose(f);
     return TZ_OK;
 }
 

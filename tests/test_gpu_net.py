@@ -117,3 +117,36 @@ def test_failed_load_keeps_old_weights(oracle, tmp_path):
     with pytest.raises(A.TakzeroError):
         net.load_tensors(bad)
     assert np.array_equal(before, net.forward_raw(states)[0])
+
+
+def test_simhash_indices_counts_and_bitvec_file(oracle, tmp_path):
+    """net4_simhash.rs:370-430 (`counts_work`, `saving_works`) on the HIP SimHash path, indices against torch."""
+    A = require_gpu()
+    import nets_torch as T
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_NET4_SIMHASH, seed=3)
+    net = A.Net(arch=A.ARCH_NET4_SIMHASH, precision=A.PREC_BF16)
+    net.load_tensors(w)
+    states = random_positions(oracle, O, 4, 4, 24, 5, max_ply=20)
+    arr = O.states_array(states)
+    planes = _planes(oracle, states).reshape(24, -1, 4, 4)
+    want = T.simhash_indices(w, planes, planes.shape[1]).astype(np.uint32)
+    got = net.hash_indices(arr)
+    assert (got == want).mean() > 0.9   # a dot product within rounding of zero may flip one of the 32 sign bits
+    acts = [O.possible_moves(oracle, s) for s in states]
+    var0 = net.policy_value_uncertainty(arr, acts)[2]
+    assert np.all(var0 == 4.0)           # nothing seen yet: maximum variance (net6_simhash.rs:246-255)
+    net.hash_indices(arr[:12], update=True)
+    var1 = net.policy_value_uncertainty(arr, acts)[2]
+    seen = np.isin(got, got[:12])
+    assert np.all(var1[seen] < 4.0) and np.all(var1[~seen] == 4.0)
+    path = tmp_path / "bitvec.bin"
+    net.save_bitset(path)
+    assert path.stat().st_size == 1 << 29
+    net2 = A.Net(arch=A.ARCH_NET4_SIMHASH, precision=A.PREC_BF16)
+    net2.load_tensors(w)
+    net2.load_bitset(path)
+    assert np.array_equal(net2.policy_value_uncertainty(arr, acts)[2], var1)
+    with pytest.raises(A.TakzeroError):
+        net2.load_bitset(tmp_path / "missing.bin")
