@@ -22,7 +22,9 @@ struct tz_net {
     uint16_t* tower_w = nullptr;  // all residual-tower layers back to back (fused tower kernel)
     float* tower_bias = nullptr;  // [2*blocks][256]
     float* heads = nullptr;  // [value conv w 256, ube conv w 256, value lin nn, ube lin nn, bv, bu, lbv, lbu]
-    ConvW rnd[2][3];         // [learning, target][input, hidden, final]
+    ConvW rnd[2][3];         // [learning, target][input, hidden, final]  (fp32 path)
+    uint16_t* rndw[3] = {nullptr, nullptr, nullptr};  // bf16 path: layer 1 = both nets side by side (2048 outputs),
+    float* rndb[3] = {nullptr, nullptr, nullptr};     // layers 2/3 = [net][...] for grouped launches
     float rnd_min = 0.0f, rnd_max = 1.0f;
     float* simhash = nullptr;    // [in_size][32] fp32, reference order (c*nn + px)
     uint32_t* bitset = nullptr;  // 2^32 bits, allocated for hash archs

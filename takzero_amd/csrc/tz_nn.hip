@@ -125,6 +125,10 @@ struct ConvArgs {
     void* out;
     int cin_pad, kc_total, ct_total, out_stride, cin_real;
     int relu, out_f32, has_res;
+    // grouped launch (blockIdx.z = group): independent layers of the same shape, e.g. the two RND networks
+    int in_stride;          // elements per input row (>= cin_pad)
+    int groups;             // grid.z
+    int in_z, w_z_frags, bias_z, out_z;  // per-group offsets: input elements, weight fragments, bias floats, output elements
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
     // fragment (tap, k-chunk, col tile) = 64 lanes x 16 B.  Buffer loads: descriptor + scalar fragment
     // offset in SGPRs, one VGPR (lane*16) for all of them -> no per-fragment 64-bit address registers.
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.w), 0, TAPS * a.kc_total * a.ct_total * 1024, 0x00020000);
+        const_cast<uint16_t*>(a.w), 0, (a.groups > 1 ? a.groups * a.w_z_frags : TAPS * a.kc_total * a.ct_total) * 1024, 0x00020000);
     const int lane16 = lane * 16;
     auto wload = [&](int tap, int kcg, int j) -> bf16x8 {
-        const int frag = (tap * a.kc_total + kcg) * a.ct_total + (ct0 + j);
+        const int frag = (int)blockIdx.z * a.w_z_frags + (tap * a.kc_total + kcg) * a.ct_total + (ct0 + j);
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0);
         return __builtin_bit_cast(bf16x8, r);
     };
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
                     const int row = id / cpr, ci = id % cpr;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (row < valid_rows)
-                        v = *reinterpret_cast<const uint4*>(in + (m0 + row) * a.cin_pad + slice * 256 + ci * 8);
+                        v = *reinterpret_cast<const uint4*>(in + (size_t)blockIdx.z * a.in_z + (m0 + row) * a.in_stride + slice * 256 + ci * 8);
                     *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v;
                 }
             }
@@ -347,13 +351,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
 #pragma unroll
     for (int j = 0; j < RN; j++) {
         const int cbase = (ct0 + j) * 16 + q * 4;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + cbase);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + (size_t)blockIdx.z * a.bias_z + cbase);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) {
             const int r = rt * 16 + lr;
             if (r >= valid_rows) continue;
             f32x4 v = acc[rt][j] + bias;
-            const size_t o = (m0 + r) * a.out_stride + cbase;
+            const size_t o = (size_t)blockIdx.z * a.out_z + (m0 + r) * a.out_stride + cbase;
             if (a.has_res) {
                 const bf16x4 rv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const uint16_t*>(a.residual) + o);
 #pragma unroll
@@ -649,16 +653,52 @@ __global__ __launch_bounds__(64) void rnd_prep_kernel(const float* planes, const
     for (int i = l; i < out_stride; i += 64) out[(size_t)pos * out_stride + i] = (T)(i < in_size ? x[i] / ss : 0.f);
 }
 
+// the same straight from the packed state (game_repr fused): one wave per board
+template <int NB>
+__global__ __launch_bounds__(64) void rnd_prep_state_kernel(const tz_state* states, const int32_t* game_index,
+                                                            const int32_t* count_dev, int count_host, int cin,
+                                                            int out_stride, __bf16* out) {
+    constexpr int NN = NB * NB;
+    const int count = count_dev ? *count_dev : count_host;
+    const int pos = blockIdx.x, l = threadIdx.x;
+    if (pos >= count) return;
+    __shared__ tz_state sh;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(states + (game_index ? game_index[pos] : pos));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&sh);
+        for (int i = l; i < (int)(sizeof(tz_state) / 4); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const tz_state* s = &sh;
+    const int fd = state_flat_diff<NB>(s);
+    const int in_size = NN * cin;
+    constexpr int PER = (NN * 40 + 63) / 64;  // cin <= 40
+    float x[PER];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = l + k * 64;
+        x[k] = i < in_size ? plane_value<NB>(s, i / cin, i % cin, fd) : 0.f;
+        ss += x[k] * x[k];
+    }
+    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = l + k * 64;
+        if (i < out_stride) out[(size_t)pos * out_stride + i] = (__bf16)(i < in_size ? x[k] / ss : 0.f);
+    }
+}
+
 // variance = clamp(max(exp(ube), local), 0, 4)  (net5.rs:271-278, net6_simhash.rs:311-318)
 __global__ __launch_bounds__(64) void rnd_finish_kernel(const float* learn, const float* target, const float* ube,
-                                                        const int32_t* count_dev, int count_host, int dim, float rmin,
-                                                        float rmax, float* variance) {
+                                                        const int32_t* count_dev, int count_host, int dim, int stride,
+                                                        float rmin, float rmax, float* variance) {
     const int count = count_dev ? *count_dev : count_host;
     const int pos = blockIdx.x, l = threadIdx.x;
     if (pos >= count) return;
     float s = 0.f;
     for (int i = l; i < dim; i += 64) {
-        const float d = learn[(size_t)pos * dim + i] - target[(size_t)pos * dim + i];
+        const float d = learn[(size_t)pos * stride + i] - target[(size_t)pos * stride + i];
         s += d * d;
     }
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
@@ -878,6 +918,8 @@ struct NetWeights {  // everything tz_net_load_weights replaces, so a failed loa
     float* tower_bias = nullptr;
     float* heads = nullptr;
     ConvW rnd[2][3];
+    uint16_t* rndw[3] = {nullptr, nullptr, nullptr};
+    float* rndb[3] = {nullptr, nullptr, nullptr};
     float rnd_min = 0.f, rnd_max = 1.f;
     float* simhash = nullptr;
 };
@@ -895,6 +937,12 @@ void free_weights(NetWeights& w) {
     w.heads = nullptr;
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) free_layer(&w.rnd[a][b]);
+    for (int l = 0; l < 3; l++) {
+        if (w.rndw[l]) (void)hipFree(w.rndw[l]);
+        if (w.rndb[l]) (void)hipFree(w.rndb[l]);
+        w.rndw[l] = nullptr;
+        w.rndb[l] = nullptr;
+    }
     if (w.simhash) (void)hipFree(w.simhash);
     w.simhash = nullptr;
 }
@@ -958,6 +1006,31 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
                 if ((rc = build_layer(prec, 1, dims[l], dims[l + 1], 256, w, {}, bias, l == 0 ? &perm : nullptr, &W.rnd[a][l])))
                     return rc;
             }
+        if (prec == TZ_PREC_BF16) {
+            // layer 1: both networks read the same input -> one GEMM with 2048 outputs
+            std::vector<float> wa, wb, ba, bb;
+            if ((rc = get_tensor(m, "rnd_learning.input_linear.weight", (size_t)1024 * in_size, wa))) return rc;
+            if ((rc = get_tensor(m, "rnd_target.input_linear.weight", (size_t)1024 * in_size, wb))) return rc;
+            if ((rc = get_tensor(m, "rnd_learning.input_linear.bias", 1024, ba))) return rc;
+            if ((rc = get_tensor(m, "rnd_target.input_linear.bias", 1024, bb))) return rc;
+            wa.insert(wa.end(), wb.begin(), wb.end());
+            ba.insert(ba.end(), bb.begin(), bb.end());
+            ConvW cat;
+            if ((rc = build_layer(prec, 1, in_size, 2048, 256, wa, {}, ba, &perm, &cat))) return rc;
+            W.rndw[0] = cat.w_mfma;
+            W.rndb[0] = cat.bias;
+            // layers 2 and 3: [net][fragments] for grouped launches
+            for (int l = 1; l < 3; l++) {
+                const size_t welems = (size_t)(W.rnd[0][l].cin_pad / 32) * (W.rnd[0][l].cout_pad / 16) * 512;
+                const size_t belems = W.rnd[0][l].cout_pad;
+                TZ_HIP(hipMalloc(&W.rndw[l], 2 * welems * 2));
+                TZ_HIP(hipMalloc(&W.rndb[l], 2 * belems * sizeof(float)));
+                for (int a = 0; a < 2; a++) {
+                    TZ_HIP(hipMemcpy(W.rndw[l] + a * welems, W.rnd[a][l].w_mfma, welems * 2, hipMemcpyDeviceToDevice));
+                    TZ_HIP(hipMemcpy(W.rndb[l] + a * belems, W.rnd[a][l].bias, belems * sizeof(float), hipMemcpyDeviceToDevice));
+                }
+            }
+        }
         if ((rc = get_tensor(m, "min", 1, t1))) return rc;
         W.rnd_min = t1[0];
         if ((rc = get_tensor(m, "max", 1, t1))) return rc;
@@ -995,11 +1068,39 @@ int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid((max_positions + P - 1) / P, n_blocks_y);
+    dim3 grid((max_positions + P - 1) / P, n_blocks_y, a.groups > 1 ? a.groups : 1);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("conv launch: ") + hipGetErrorString(e));
     return TZ_OK;
+}
+
+// Linear layers of the RND MLP, `groups` independent networks per launch (128 positions per workgroup)
+int linear_grouped_bf16(const uint16_t* w, const float* bias, int groups, int cin_pad, int cout_pad, const void* in,
+                        int in_stride, int in_z, void* out, int out_stride, int out_z, bool relu, bool out_f32,
+                        const int32_t* count_dev, int count_host, int max_positions, hipStream_t st) {
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = in;
+    a.count_dev = count_dev;
+    a.count_host = count_host;
+    a.w = w;
+    a.bias = bias;
+    a.out = out;
+    a.cin_pad = cin_pad;
+    a.kc_total = cin_pad / 32;
+    a.ct_total = cout_pad / 16;
+    a.out_stride = out_stride;
+    a.cin_real = cin_pad;
+    a.relu = relu;
+    a.out_f32 = out_f32;
+    a.in_stride = in_stride;
+    a.groups = groups;
+    a.in_z = in_z;
+    a.w_z_frags = a.kc_total * a.ct_total;
+    a.bias_z = cout_pad;
+    a.out_z = out_z;
+    return launch_conv<1, 128, 8, 2, 1, false, false>(a, max_positions, cout_pad / 256, st);
 }
 
 template <int NB>
@@ -1039,6 +1140,9 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     a.relu = relu;
     a.out_f32 = out_f32;
     a.has_res = residual != nullptr;
+    a.in_stride = L.cin_pad;
+    a.groups = 1;
+    a.in_z = a.w_z_frags = a.bias_z = a.out_z = 0;
     if (!board) return launch_conv<1, 64, 8, 2, 1, false, false>(a, max_positions, L.cout_pad / 256, st);
     switch (net->n) {
         case 3: return conv_board<3>(a, L.cout_pad, in == nullptr, max_positions, st);
@@ -1161,8 +1265,8 @@ int tz_net_ensure_batch(tz_net* net, int batch) {
     if (net->has_rnd) {
         const size_t in_pad = (size_t)(net->cin * net->nn + 31) / 32 * 32;
         TZ_HIP(hipMalloc(&net->rnd_in, (size_t)batch * in_pad * esz));
-        TZ_HIP(hipMalloc(&net->rnd_h1, (size_t)batch * 1024 * esz));
-        TZ_HIP(hipMalloc(&net->rnd_h2, (size_t)batch * 1024 * esz));
+        TZ_HIP(hipMalloc(&net->rnd_h1, (size_t)batch * 2048 * esz));
+        TZ_HIP(hipMalloc(&net->rnd_h2, (size_t)batch * 2048 * esz));
         TZ_HIP(hipMalloc(&net->rnd_out, (size_t)2 * batch * 512 * sizeof(float)));
     }
     net->max_batch = batch;
@@ -1176,7 +1280,7 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     int rc;
     const bool bf = net->precision == TZ_PREC_BF16;
     const int nn = net->nn;
-    const bool need_planes = !bf || net->has_rnd || net->has_hash;
+    const bool need_planes = !bf || net->has_hash;
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
     if (bf) {
@@ -1248,18 +1352,24 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         const int in_size = net->cin * nn, in_pad = (in_size + 31) / 32 * 32;
         float* outs[2] = {net->rnd_out, net->rnd_out + (size_t)net->max_batch * 512};
         if (bf) {
-            rnd_prep_kernel<__bf16><<<max_positions, 64, 0, st>>>(net->planes, count_dev, count_host, in_size, in_pad, (__bf16*)net->rnd_in);
-            for (int a = 0; a < 2; a++) {
-                if ((rc = conv_bf16(net, net->rnd[a][0], net->rnd_in, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
-                                    net->rnd_h1, 1024, true, false, false, st)))
-                    return rc;
-                if ((rc = conv_bf16(net, net->rnd[a][1], net->rnd_h1, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
-                                    net->rnd_h2, 1024, true, false, false, st)))
-                    return rc;
-                if ((rc = conv_bf16(net, net->rnd[a][2], net->rnd_h2, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
-                                    outs[a], 512, false, true, false, st)))
-                    return rc;
+            // 3 launches: input planes straight from the packed states, layer 1 of both nets as one GEMM,
+            // layers 2 and 3 as grouped launches (blockIdx.z = net)
+            switch (net->n) {
+                case 5: rnd_prep_state_kernel<5><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (__bf16*)net->rnd_in); break;
+                default: return tz_fail(TZ_EINVAL, "RND is a net5 (5x5) feature");
             }
+            float* o = net->rnd_out;
+            if ((rc = linear_grouped_bf16(net->rndw[0], net->rndb[0], 1, in_pad, 2048, net->rnd_in, in_pad, 0, net->rnd_h1, 2048, 0,
+                                          true, false, count_dev, count_host, max_positions, st)))
+                return rc;
+            if ((rc = linear_grouped_bf16(net->rndw[1], net->rndb[1], 2, 1024, 1024, net->rnd_h1, 2048, 1024, net->rnd_h2, 2048, 1024,
+                                          true, false, count_dev, count_host, max_positions, st)))
+                return rc;
+            if ((rc = linear_grouped_bf16(net->rndw[2], net->rndb[2], 2, 1024, 512, net->rnd_h2, 2048, 1024, o, 1024, 512, false, true,
+                                          count_dev, count_host, max_positions, st)))
+                return rc;
+            rnd_finish_kernel<<<max_positions, 64, 0, st>>>(o, o + 512, net->ube, count_dev, count_host, 512, 1024, net->rnd_min,
+                                                            net->rnd_max, net->variance);
         } else {
             rnd_prep_kernel<float><<<max_positions, 64, 0, st>>>(net->planes, count_dev, count_host, in_size, in_pad, (float*)net->rnd_in);
             for (int a = 0; a < 2; a++) {
@@ -1274,8 +1384,9 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
                     return rc;
             }
         }
-        rnd_finish_kernel<<<max_positions, 64, 0, st>>>(outs[0], outs[1], net->ube, count_dev, count_host, 512, net->rnd_min,
-                                                        net->rnd_max, net->variance);
+        if (!bf)
+            rnd_finish_kernel<<<max_positions, 64, 0, st>>>(outs[0], outs[1], net->ube, count_dev, count_host, 512, 512, net->rnd_min,
+                                                            net->rnd_max, net->variance);
     } else if (net->has_hash) {
         simhash_kernel<<<max_positions, 64, 0, st>>>(net->planes, net->simhash, net->bitset, count_dev, count_host, nn, net->cin,
                                                      net->aux, nullptr);
@@ -1366,6 +1477,12 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) old.rnd[a][b] = net->rnd[a][b];
+    for (int l = 0; l < 3; l++) {
+        old.rndw[l] = net->rndw[l];
+        old.rndb[l] = net->rndb[l];
+        net->rndw[l] = W.rndw[l];
+        net->rndb[l] = W.rndb[l];
+    }
     old.simhash = net->simhash;
     net->conv_in = W.conv_in;
     net->policy = W.policy;
@@ -1419,6 +1536,8 @@ int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, floa
     a.out_stride = FILTERS;
     a.cin_real = L.cin;
     a.relu = 1;
+    a.in_stride = L.cin_pad;
+    a.groups = 1;
     {   // pseudo-random bf16 activations in [-1,1): zero or constant operands flatter the clock (DVFS)
         std::vector<uint16_t> h((size_t)positions * 25 * FILTERS);
         uint32_t x = 12345u;
@@ -1537,6 +1656,10 @@ int tz_net_destroy(tz_net* net) {
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) old.rnd[a][b] = net->rnd[a][b];
+    for (int l = 0; l < 3; l++) {
+        old.rndw[l] = net->rndw[l];
+        old.rndb[l] = net->rndb[l];
+    }
     old.simhash = net->simhash;
     free_weights(old);
     void* bufs[] = {net->act_a, net->act_b, net->act_c, net->planes, net->policy_out, net->value, net->ube,
