@@ -46,8 +46,14 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError("%s is missing: build it with `python -m takzero_amd.build` (hipcc, gfx950). "
-                          "takzero_amd has no CPU fallback." % LIB_PATH)
+        # not built yet: compile it in-tree if hipcc is here (that is still the HIP path, never a CPU substitute)
+        try:
+            from . import build as _build
+
+            _build.build()
+        except Exception as e:
+            raise ImportError("%s is missing and could not be built (%s): run `python -m takzero_amd.build` "
+                              "(hipcc, gfx950).  takzero_amd has no CPU fallback." % (LIB_PATH, e))
     lib = C.CDLL(LIB_PATH)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.tz_last_error.restype = C.c_char_p
