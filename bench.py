@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--capacity", type=int, default=0)
+    ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16",
+                    help="16-bit storage type of the MFMA path (same kernels, same rate; f16 is within 1e-3 of fp32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +120,7 @@ def main():
     from takzero_amd import selfplay as SP
     from takzero_amd import weights as W
 
-    net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_F16 if args.precision == "f16" else A.PREC_BF16)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
     sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank)
@@ -170,7 +172,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": args.precision,
             "data": "synthetic (random-init net5 weights seed 123, random symmetric openings)",
             "config": {"workload": "5x5 Tak self-play, %d concurrent games/GPU, %d sims/move, PUCT+Dirichlet, net5 (BASELINE configs[1])"
                                    % (args.games, args.sims),

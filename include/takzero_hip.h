@@ -96,7 +96,8 @@ typedef struct tz_search tz_search; /* opaque: BatchedMCTS<B, Game<N,HALF_KOMI>>
 
 /* arithmetic of the trunk */
 #define TZ_PREC_BF16 0 /* NHWC bf16 activations/weights, fp32 accumulate on MFMA (throughput path) */
-#define TZ_PREC_F32 1  /* fp32 everywhere (validation path for the 1e-3 logit gate)                 */
+#define TZ_PREC_F32 1  /* fp32 everywhere on plain FMA kernels (validation path)                          */
+#define TZ_PREC_F16 2  /* same MFMA kernels as bf16 with IEEE fp16 storage: logits within 1e-3 of fp32      */
 
 /* built-in agents for tz_search_create (takzero/src/search/agent.rs:16-87) */
 #define TZ_AGENT_NET 0

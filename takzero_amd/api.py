@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import ROOT_INFO_DTYPE, STATE_DTYPE, TakzeroError, check
 
 ARCH_NET4_SIMHASH, ARCH_NET5, ARCH_NET6_SIMHASH, ARCH_TEST = 4, 5, 6, 100
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
 AGENT_NET, AGENT_DUMMY, AGENT_SIMPLE = 0, 1, 2
 EVAL_VALUE, EVAL_WIN, EVAL_LOSS, EVAL_DRAW = 0, 1, 2, 3
 TERMINAL_NONE, TERMINAL_WIN, TERMINAL_LOSS, TERMINAL_DRAW = -1, 0, 1, 2

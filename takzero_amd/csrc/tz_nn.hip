@@ -24,10 +24,31 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// The 16-bit MFMA path is written once for two storage types of equal MFMA rate: bf16 (TZ_PREC_BF16, the
+// benchmarked default) and IEEE fp16 (TZ_PREC_F16: 3 more mantissa bits; stays within 1e-3 of the fp32 LibTorch
+// logits through the 41 stacked convs, which bf16 only just misses).
+template <typename ET>
+struct Elem;
+template <>
+struct Elem<__bf16> {
+    typedef bf16x8 x8;
+    typedef bf16x4 x4;
+    static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Elem<_Float16> {
+    typedef f16x8 x8;
+    typedef f16x4 x4;
+    static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
 
 // LDS activation tile, plane-major: [k-chunk kc (32 channels = 64 B)][row][64 B].  Inside a 64-B row segment the
 // four 16-B pieces q are rotated by 2*((row>>2)&1):  piece q of row r sits at (q + 2*((r>>2)&1)) & 3.  With the
@@ -164,8 +185,10 @@ __device__ __forceinline__ void tap_bases_rc(int tap, int lr, int q, int rows, i
 // SINGLE: the whole reduction is one 256-channel slice (tower and policy convs): unrolled tile loader,
 // weight fragments prefetched two k-steps ahead.
 // NW = waves per workgroup; a workgroup covers NW*RN*16 output channels of P boards.
-template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false, int NW = 8, int LAYOUT = 1>
+template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false, int NW = 8, int LAYOUT = 1, typename ET = __bf16>
 __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  // 2 waves per SIMD: <= 256 registers
+    typedef typename Elem<ET>::x8 ex8;
+    typedef typename Elem<ET>::x4 ex4;
     constexpr int NT = NW * 64;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
@@ -185,10 +208,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.w), 0, (a.groups > 1 ? a.groups * a.w_z_frags : TAPS * a.kc_total * a.ct_total) * 1024, 0x00020000);
     const int lane16 = lane * 16;
-    auto wload = [&](int tap, int kcg, int j) -> bf16x8 {
+    auto wload = [&](int tap, int kcg, int j) -> ex8 {
         const int frag = (int)blockIdx.z * a.w_z_frags + (tap * a.kc_total + kcg) * a.ct_total + (ct0 + j);
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0);
-        return __builtin_bit_cast(bf16x8, r);
+        return __builtin_bit_cast(ex8, r);
     };
     f32x4 acc[RT][RN];
 
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
             }
         }
         // weight ring: 4 slots, slot = kc & 3 (compile time, 8 % 4 == 0), filled two k-steps ahead
-        bf16x8 bq[4][RN];
+        ex8 bq[4][RN];
 #pragma unroll
         for (int j = 0; j < RN; j++) {
             bq[0][j] = wload(0, 0, j);
@@ -227,9 +250,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
         // whole step to land; the weight fragments of step s+2 are issued at the top of step s.
         int abase[RT];
         tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr, q, ROWS, ZROW, abase);
-        bf16x8 av[RT];
+        ex8 av[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+        for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
         for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
             for (int kc = 0; kc < 8; kc++) {
@@ -261,10 +284,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
                     for (int j = 0; j < RN; j++)
-                        acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kc & 3][j], av[rt], acc[rt][j], 0, 0, 0);
+                        acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
                     if constexpr ((ABL & 1) == 0) {
-                        if (kc < 7) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + (kc + 1 - (LAYOUT == 1 && kc >= 4 ? 4 : 0)) * KSTEP);
-                        else av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+                        if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (LAYOUT == 1 && kc >= 4 ? 4 : 0)) * KSTEP);
+                        else av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
                     }
                 }
             }
@@ -298,13 +321,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
                         fd = state_flat_diff<NB>(s);
                     }
                     for (int c8 = 0; c8 < cpr; c8++) {
-                        bf16x8 v;
+                        ex8 v;
 #pragma unroll
                         for (int k = 0; k < 8; k++) {
                             const int c = c8 * 8 + k;
-                            v[k] = (__bf16)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
+                            v[k] = (ET)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
                         }
-                        *reinterpret_cast<bf16x8*>(lds + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = v;
+                        *reinterpret_cast<ex8*>(lds + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = v;
                     }
                 }
             } else {
@@ -318,14 +341,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
                 }
             }
             __syncthreads();
-            bf16x8 bnext[RN];
+            ex8 bnext[RN];
 #pragma unroll
             for (int j = 0; j < RN; j++) bnext[j] = wload(0, slice * 8, j);
             for (int tap = 0; tap < TAPS; tap++) {
                 int abase[RT];
                 tap_bases<NB, RT, TAPS, LAYOUT>(yx, tap, lr, q, ZROW, abase);
                 for (int kc = 0; kc < kcs; kc++) {
-                    bf16x8 bcur[RN];
+                    ex8 bcur[RN];
 #pragma unroll
                     for (int j = 0; j < RN; j++) bcur[j] = bnext[j];
                     if (kc + 1 < kcs) {
@@ -337,10 +360,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
                     }
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
-                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + kc * KSTEP);
+                        const ex8 av = *reinterpret_cast<const ex8*>(lds + abase[rt] + kc * KSTEP);
 #pragma unroll
                         for (int j = 0; j < RN; j++)
-                            acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[j], av, acc[rt][j], 0, 0, 0);
+                            acc[rt][j] = Elem<ET>::mfma(bcur[j], av, acc[rt][j]);
                     }
                 }
             }
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
             f32x4 v = acc[rt][j] + bias;
             const size_t o = (size_t)blockIdx.z * a.out_z + (m0 + r) * a.out_stride + cbase;
             if (a.has_res) {
-                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const uint16_t*>(a.residual) + o);
+                const ex4 rv = *reinterpret_cast<const ex4*>(reinterpret_cast<const uint16_t*>(a.residual) + o);
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[k] += (float)rv[k];
             }
@@ -370,10 +393,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  //
             if (a.out_f32) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = v;
             } else {
-                bf16x4 ov;
+                ex4 ov;
 #pragma unroll
-                for (int k = 0; k < 4; k++) ov[k] = (__bf16)v[k];
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(a.out) + o) = ov;
+                for (int k = 0; k < 4; k++) ov[k] = (ET)v[k];
+                *reinterpret_cast<ex4*>(reinterpret_cast<uint16_t*>(a.out) + o) = ov;
             }
         }
     }
@@ -399,8 +422,10 @@ struct TowerArgs {
 
 // OPT: bit 0 = fetch the next layer's first weight fragments during the last two k-steps (A/B switch for
 // tz_debug_tower_bench; shipped value in launch_tower)
-template <int NB, int P, int OPT = 0>
+template <int NB, int P, int OPT = 0, typename ET = __bf16>
 __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
+    typedef typename Elem<ET>::x8 ex8;
+    typedef typename Elem<ET>::x4 ex4;
     constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB, KSTEP = PLANE;
@@ -418,10 +443,10 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
     const int lane16 = lane * 16;
-    auto wload = [&](int layer, int tap, int kc, int j) -> bf16x8 {
+    auto wload = [&](int layer, int tap, int kc, int j) -> ex8 {
         const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0);
-        return __builtin_bit_cast(bf16x8, r);
+        return __builtin_bit_cast(ex8, r);
     };
     {   // tower input tile: every load in flight before the first LDS store
         constexpr int NLOAD = (LROWS * 32 + NT - 1) / NT;
@@ -446,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
         obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
 
     f32x4 acc[RT][RN];
-    bf16x8 bq[4][RN];  // weight ring; slots 0/1 of the next layer are fetched during the last two k-steps of this one
+    ex8 bq[4][RN];  // weight ring; slots 0/1 of the next layer are fetched during the last two k-steps of this one
     for (int layer = 0; layer < a.nlayers; layer++) {
         if ((layer & 1) == 0) {  // first conv of a block starts from its bias; the second from x + bias (below)
 #pragma unroll
@@ -478,9 +503,9 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
             asm volatile("" : "+v"(lr_t));
             tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr_t, q, ROWS, ZROW, abase);
         }
-        bf16x8 av[RT];
+        ex8 av[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+        for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
         for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
             for (int kc = 0; kc < 8; kc++) {
@@ -511,9 +536,9 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
                     for (int j = 0; j < RN; j++)
-                        acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[kc & 3][j], av[rt], acc[rt][j], 0, 0, 0);
-                    if (kc < 7) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * KSTEP);
-                    else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const bf16x8*>(lds + abase[rt]);
+                        acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
+                    if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * KSTEP);
+                    else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
                 }
             }
         }
@@ -527,10 +552,10 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
                     const int r = rt * 16 + lr;
-                    bf16x4 pk;
+                    ex4 pk;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = (__bf16)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
-                    if (r < valid_rows) *reinterpret_cast<bf16x4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
+                    for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    if (r < valid_rows) *reinterpret_cast<ex4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
                 }
             }
             break;
@@ -543,12 +568,12 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
             if (to_second) b4 = *reinterpret_cast<const f32x4*>(a.bias + (layer + 1) * FILTERS + (ct0 + j) * 16 + q * 4);
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                bf16x4* slot = reinterpret_cast<bf16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
-                bf16x4 pk;
+                ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
+                ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = (__bf16)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                 if (to_second) {
-                    const bf16x4 xv = *slot;
+                    const ex4 xv = *slot;
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
                 }
@@ -654,10 +679,10 @@ __global__ __launch_bounds__(64) void rnd_prep_kernel(const float* planes, const
 }
 
 // the same straight from the packed state (game_repr fused): one wave per board
-template <int NB>
+template <int NB, typename ET>
 __global__ __launch_bounds__(64) void rnd_prep_state_kernel(const tz_state* states, const int32_t* game_index,
                                                             const int32_t* count_dev, int count_host, int cin,
-                                                            int out_stride, __bf16* out) {
+                                                            int out_stride, ET* out) {
     constexpr int NN = NB * NB;
     const int count = count_dev ? *count_dev : count_host;
     const int pos = blockIdx.x, l = threadIdx.x;
@@ -685,7 +710,7 @@ __global__ __launch_bounds__(64) void rnd_prep_state_kernel(const tz_state* stat
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = l + k * 64;
-        if (i < out_stride) out[(size_t)pos * out_stride + i] = (__bf16)(i < in_size ? x[k] / ss : 0.f);
+        if (i < out_stride) out[(size_t)pos * out_stride + i] = (ET)(i < in_size ? x[k] / ss : 0.f);
     }
 }
 
@@ -786,6 +811,13 @@ uint16_t f2bf(float f) {  // round to nearest even; NaN stays NaN
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+uint16_t f2h(float f) {  // IEEE binary16, round to nearest even (host clang has _Float16)
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
 struct Tensor {
     std::vector<uint32_t> dims;
     const float* data;
@@ -863,7 +895,7 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
     for (int co = 0; co < cout; co++) b[co] = bias.empty() ? 0.0f : bias[co];
     int rc = upload(b, &L->bias);
     if (rc) return rc;
-    if (precision == TZ_PREC_BF16) {
+    if (precision != TZ_PREC_F32) {
         const int kc_total = L->cin_pad / 32, ct_total = L->cout_pad / 16;
         std::vector<uint16_t> p((size_t)taps * kc_total * ct_total * 64 * 8, 0);
         for (int t = 0; t < taps; t++)
@@ -875,7 +907,7 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
                         for (int j = 0; j < 8; j++) {
                             const int ci = kc * 32 + 8 * (lane >> 4) + j;
                             if (ci >= cin) continue;
-                            p[((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j] = f2bf(W(co, ci, t));
+                            p[((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j] = precision == TZ_PREC_F16 ? f2h(W(co, ci, t)) : f2bf(W(co, ci, t));
                         }
                     }
         return upload(p, &L->w_mfma);
@@ -962,7 +994,7 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
             if ((rc = bn_fold(m, p + ".batch_norm", FILTERS, scale, bias))) return rc;
             if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h]))) return rc;
         }
-    if (prec == TZ_PREC_BF16 && net->blocks > 0) {  // the fused tower kernel reads all layers from one buffer
+    if (prec != TZ_PREC_F32 && net->blocks > 0) {  // the fused tower kernel reads all layers from one buffer
         const size_t layer_elems = (size_t)9 * 8 * 16 * 64 * 8, nl = W.res.size();
         TZ_HIP(hipMalloc(&W.tower_w, nl * layer_elems * 2));
         TZ_HIP(hipMalloc(&W.tower_bias, nl * FILTERS * sizeof(float)));
@@ -1006,7 +1038,7 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
                 if ((rc = build_layer(prec, 1, dims[l], dims[l + 1], 256, w, {}, bias, l == 0 ? &perm : nullptr, &W.rnd[a][l])))
                     return rc;
             }
-        if (prec == TZ_PREC_BF16) {
+        if (prec != TZ_PREC_F32) {
             // layer 1: both networks read the same input -> one GEMM with 2048 outputs
             std::vector<float> wa, wb, ba, bb;
             if ((rc = get_tensor(m, "rnd_learning.input_linear.weight", (size_t)1024 * in_size, wa))) return rc;
@@ -1058,11 +1090,11 @@ int conv_cfg() {
     return cfg;
 }
 
-template <int NB, int P, int NW, int RN, int TAPS, bool FROM_STATE, bool SINGLE, int ABL = 0, int LAYOUT = 1>
+template <int NB, int P, int NW, int RN, int TAPS, bool FROM_STATE, bool SINGLE, int ABL = 0, int LAYOUT = 1, typename ET = __bf16>
 int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_t st) {
     constexpr int NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = LdsImg<LAYOUT>::bytes(LROWS);
-    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, ABL, SINGLE, NW, LAYOUT>;
+    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, ABL, SINGLE, NW, LAYOUT, ET>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1076,7 +1108,7 @@ int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_
 }
 
 // Linear layers of the RND MLP, `groups` independent networks per launch (128 positions per workgroup)
-int linear_grouped_bf16(const uint16_t* w, const float* bias, int groups, int cin_pad, int cout_pad, const void* in,
+int linear_grouped_bf16(int precision, const uint16_t* w, const float* bias, int groups, int cin_pad, int cout_pad, const void* in,
                         int in_stride, int in_z, void* out, int out_stride, int out_z, bool relu, bool out_f32,
                         const int32_t* count_dev, int count_host, int max_positions, hipStream_t st) {
     ConvArgs a;
@@ -1100,22 +1132,35 @@ int linear_grouped_bf16(const uint16_t* w, const float* bias, int groups, int ci
     a.w_z_frags = a.kc_total * a.ct_total;
     a.bias_z = cout_pad;
     a.out_z = out_z;
+    if (precision == TZ_PREC_F16) return launch_conv<1, 128, 8, 2, 1, false, false, 0, 1, _Float16>(a, max_positions, cout_pad / 256, st);
     return launch_conv<1, 128, 8, 2, 1, false, false>(a, max_positions, cout_pad / 256, st);
 }
 
-template <int NB>
+template <int NB, typename ET>
 int conv_board(const ConvArgs& a, int cout_pad, bool from_state, int max_positions, hipStream_t st) {
     constexpr int PA = ppt_for(NB), PB = ppt_small(NB);
     const bool wide = cout_pad % 256 == 0;
     const int by = wide ? cout_pad / 256 : cout_pad / 128;
     if (conv_cfg() == 0) {
-        if (from_state) return launch_conv<NB, PA, 8, 2, 9, true, false>(a, max_positions, by, st);
-        if (wide) return launch_conv<NB, PA, 8, 2, 9, false, true>(a, max_positions, by, st);
-        return launch_conv<NB, PA, 8, 1, 9, false, true>(a, max_positions, by, st);
+        if (from_state) return launch_conv<NB, PA, 8, 2, 9, true, false, 0, 1, ET>(a, max_positions, by, st);
+        if (wide) return launch_conv<NB, PA, 8, 2, 9, false, true, 0, 1, ET>(a, max_positions, by, st);
+        return launch_conv<NB, PA, 8, 1, 9, false, true, 0, 1, ET>(a, max_positions, by, st);
     }
-    if (from_state) return launch_conv<NB, PB, 4, 4, 9, true, false>(a, max_positions, by, st);
-    if (wide) return launch_conv<NB, PB, 4, 4, 9, false, true>(a, max_positions, by, st);
-    return launch_conv<NB, PB, 4, 2, 9, false, true>(a, max_positions, by, st);
+    if (from_state) return launch_conv<NB, PB, 4, 4, 9, true, false, 0, 1, ET>(a, max_positions, by, st);
+    if (wide) return launch_conv<NB, PB, 4, 4, 9, false, true, 0, 1, ET>(a, max_positions, by, st);
+    return launch_conv<NB, PB, 4, 2, 9, false, true, 0, 1, ET>(a, max_positions, by, st);
+}
+
+template <typename ET>
+int conv_dispatch(int n, bool board, const ConvArgs& a, int cout_pad, bool from_state, int max_positions, hipStream_t st) {
+    if (!board) return launch_conv<1, 64, 8, 2, 1, false, false, 0, 1, ET>(a, max_positions, cout_pad / 256, st);
+    switch (n) {
+        case 3: return conv_board<3, ET>(a, cout_pad, from_state, max_positions, st);
+        case 4: return conv_board<4, ET>(a, cout_pad, from_state, max_positions, st);
+        case 5: return conv_board<5, ET>(a, cout_pad, from_state, max_positions, st);
+        case 6: return conv_board<6, ET>(a, cout_pad, from_state, max_positions, st);
+    }
+    return tz_fail(TZ_EINVAL, "conv: unsupported board size");
 }
 
 // one bf16 layer.  in==nullptr -> first layer from packed states.
@@ -1143,14 +1188,8 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     a.in_stride = L.cin_pad;
     a.groups = 1;
     a.in_z = a.w_z_frags = a.bias_z = a.out_z = 0;
-    if (!board) return launch_conv<1, 64, 8, 2, 1, false, false>(a, max_positions, L.cout_pad / 256, st);
-    switch (net->n) {
-        case 3: return conv_board<3>(a, L.cout_pad, in == nullptr, max_positions, st);
-        case 4: return conv_board<4>(a, L.cout_pad, in == nullptr, max_positions, st);
-        case 5: return conv_board<5>(a, L.cout_pad, in == nullptr, max_positions, st);
-        case 6: return conv_board<6>(a, L.cout_pad, in == nullptr, max_positions, st);
-    }
-    return tz_fail(TZ_EINVAL, "conv: unsupported board size");
+    if (net->precision == TZ_PREC_F16) return conv_dispatch<_Float16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
+    return conv_dispatch<__bf16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
 }
 
 bool tower_enabled() {
@@ -1162,11 +1201,11 @@ bool tower_enabled() {
     return on != 0;
 }
 
-template <int NB, int OPT = 0>
+template <int NB, int OPT = 0, typename ET = __bf16>
 int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8;
-    auto kern = tower_mfma_kernel<NB, P, OPT>;
+    auto kern = tower_mfma_kernel<NB, P, OPT, ET>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1188,11 +1227,12 @@ int tower_bf16(tz_net* net, const void* in, void* out, const int32_t* count_dev,
     a.count_dev = count_dev;
     a.count_host = count_host;
     a.nlayers = 2 * net->blocks;
+    const bool h = net->precision == TZ_PREC_F16;
     switch (net->n) {
-        case 3: return launch_tower<3>(a, max_positions, st);
-        case 4: return launch_tower<4>(a, max_positions, st);
-        case 5: return launch_tower<5>(a, max_positions, st);
-        case 6: return launch_tower<6>(a, max_positions, st);
+        case 3: return h ? launch_tower<3, 0, _Float16>(a, max_positions, st) : launch_tower<3>(a, max_positions, st);
+        case 4: return h ? launch_tower<4, 0, _Float16>(a, max_positions, st) : launch_tower<4>(a, max_positions, st);
+        case 5: return h ? launch_tower<5, 0, _Float16>(a, max_positions, st) : launch_tower<5>(a, max_positions, st);
+        case 6: return h ? launch_tower<6, 0, _Float16>(a, max_positions, st) : launch_tower<6>(a, max_positions, st);
     }
     return tz_fail(TZ_EINVAL, "tower: unsupported board size");
 }
@@ -1251,7 +1291,7 @@ int tz_net_ensure_batch(tz_net* net, int batch) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;
     }
-    const size_t esz = net->precision == TZ_PREC_BF16 ? 2 : 4;
+    const size_t esz = net->precision != TZ_PREC_F32 ? 2 : 4;
     const size_t rows = (size_t)batch * net->nn;
     TZ_HIP(hipMalloc(&net->act_a, rows * FILTERS * esz));
     TZ_HIP(hipMalloc(&net->act_b, rows * FILTERS * esz));
@@ -1278,7 +1318,7 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     if (!net->loaded) return tz_fail(TZ_ESTATE, "network has no weights loaded");
     if (max_positions > net->max_batch) return tz_fail(TZ_EINVAL, "forward: batch exceeds the network's buffers");
     int rc;
-    const bool bf = net->precision == TZ_PREC_BF16;
+    const bool bf = net->precision != TZ_PREC_F32;  // 16-bit MFMA path (bf16 or fp16 storage)
     const int nn = net->nn;
     const bool need_planes = !bf || net->has_hash;
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
@@ -1327,7 +1367,10 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         if ((rc = conv_bf16(net, net->policy, x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
                             net->policy_out, net->pol_stride, false, true, true, st)))
             return rc;
-        heads_kernel<__bf16><<<max_positions, 64, 0, st>>>((const __bf16*)x, net->heads, count_dev, count_host, nn, net->value, net->ube);
+        if (net->precision == TZ_PREC_F16)
+            heads_kernel<_Float16><<<max_positions, 64, 0, st>>>((const _Float16*)x, net->heads, count_dev, count_host, nn, net->value, net->ube);
+        else
+            heads_kernel<__bf16><<<max_positions, 64, 0, st>>>((const __bf16*)x, net->heads, count_dev, count_host, nn, net->value, net->ube);
     } else {
         float *fx = (float*)x, *ft = (float*)t, *fy = (float*)y;
         if ((rc = conv_f32(net, net->conv_in, net->planes, net->cin, count_dev, count_host, max_positions, nullptr, fx, FILTERS,
@@ -1355,17 +1398,22 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
             // 3 launches: input planes straight from the packed states, layer 1 of both nets as one GEMM,
             // layers 2 and 3 as grouped launches (blockIdx.z = net)
             switch (net->n) {
-                case 5: rnd_prep_state_kernel<5><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (__bf16*)net->rnd_in); break;
+                case 5:
+                    if (net->precision == TZ_PREC_F16)
+                        rnd_prep_state_kernel<5, _Float16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (_Float16*)net->rnd_in);
+                    else
+                        rnd_prep_state_kernel<5, __bf16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (__bf16*)net->rnd_in);
+                    break;
                 default: return tz_fail(TZ_EINVAL, "RND is a net5 (5x5) feature");
             }
             float* o = net->rnd_out;
-            if ((rc = linear_grouped_bf16(net->rndw[0], net->rndb[0], 1, in_pad, 2048, net->rnd_in, in_pad, 0, net->rnd_h1, 2048, 0,
+            if ((rc = linear_grouped_bf16(net->precision, net->rndw[0], net->rndb[0], 1, in_pad, 2048, net->rnd_in, in_pad, 0, net->rnd_h1, 2048, 0,
                                           true, false, count_dev, count_host, max_positions, st)))
                 return rc;
-            if ((rc = linear_grouped_bf16(net->rndw[1], net->rndb[1], 2, 1024, 1024, net->rnd_h1, 2048, 1024, net->rnd_h2, 2048, 1024,
+            if ((rc = linear_grouped_bf16(net->precision, net->rndw[1], net->rndb[1], 2, 1024, 1024, net->rnd_h1, 2048, 1024, net->rnd_h2, 2048, 1024,
                                           true, false, count_dev, count_host, max_positions, st)))
                 return rc;
-            if ((rc = linear_grouped_bf16(net->rndw[2], net->rndb[2], 2, 1024, 512, net->rnd_h2, 2048, 1024, o, 1024, 512, false, true,
+            if ((rc = linear_grouped_bf16(net->precision, net->rndw[2], net->rndb[2], 2, 1024, 512, net->rnd_h2, 2048, 1024, o, 1024, 512, false, true,
                                           count_dev, count_host, max_positions, st)))
                 return rc;
             rnd_finish_kernel<<<max_positions, 64, 0, st>>>(o, o + 512, net->ube, count_dev, count_host, 512, 1024, net->rnd_min,
@@ -1421,7 +1469,8 @@ int tz_net_create(int board_n, int arch, int device_id, int precision, int block
     else if (arch != TZ_ARCH_TEST) return tz_fail(TZ_EINVAL, "tz_net_create: unknown architecture");
     if (board_n && board_n != n) return tz_fail(TZ_EINVAL, "tz_net_create: board size does not match the architecture");
     if (n < 3 || n > 6) return tz_fail(TZ_EINVAL, "tz_net_create: board size must be 3..6");
-    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32) return tz_fail(TZ_EINVAL, "tz_net_create: bad precision");
+    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16)
+        return tz_fail(TZ_EINVAL, "tz_net_create: bad precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return tz_fail(TZ_EDEVICE, "tz_net_create: no HIP device available (the HIP path has no CPU fallback)");

@@ -26,7 +26,7 @@ def _agent_over(net):
 # (100,...) small nets; (5,...) full net5 = config 2 at test size; (4,...) config 1: 4x4, 64 games, 100 sims/move,
 # net4_simhash; (6,...) config 4 at test size: 6x6, net6_simhash
 @pytest.mark.parametrize("arch,n,blocks,prec,B,sims,moves", [(100, 5, 2, 0, 24, 30, 5), (100, 4, 1, 1, 16, 25, 4),
-                                                             (5, 5, 20, 0, 12, 24, 3), (4, 4, 16, 0, 64, 100, 2),
+                                                             (5, 5, 20, 0, 12, 24, 3), (5, 5, 20, 2, 12, 24, 2), (4, 4, 16, 0, 64, 100, 2),
                                                              (6, 6, 16, 0, 8, 40, 2)])
 def test_engine_matches_oracle_search_with_same_net(oracle, arch, n, blocks, prec, B, sims, moves):
     A = require_gpu()

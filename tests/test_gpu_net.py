@@ -84,6 +84,16 @@ def test_bf16_mfma_path_close_to_torch(oracle, arch, n, blocks, batch):
     assert err["value"] < BF16_REL_TOL and err["ube"] < 2 * BF16_REL_TOL
 
 
+@pytest.mark.parametrize("arch,n,blocks,batch", [(5, 5, 20, 21), (100, 5, 3, 19), (6, 6, 16, 7), (4, 4, 16, 15), (100, 3, 2, 33)])
+def test_f16_mfma_path_within_1e_3_of_torch(oracle, arch, n, blocks, batch):
+    """TZ_PREC_F16: the same MFMA kernels with IEEE fp16 storage meet the north star's 1e-3 logit/value tolerance
+    against the fp32 LibTorch graph, on the full nets, at the bf16 path's speed."""
+    A = require_gpu()
+    err = _compare(A, oracle, arch, n, blocks, A.PREC_F16, batch, 44, False)
+    print("f16 errors", err)
+    assert err["policy"] < F32_TOL and err["value"] < F32_TOL and err["ube"] < 2 * F32_TOL
+
+
 def test_forward_is_batch_composition_independent(oracle):
     """A position's outputs do not depend on its slot or its neighbours (needed so that the oracle can
     replay the engine's network calls one position at a time)."""
