@@ -32,8 +32,17 @@ sys.path.insert(0, ROOT)
 N_BOARD, HALF_KOMI, GAMES, SIMS = 5, 4, 4096, 400
 FLOP_PER_POSITION = 1.2071e9          # net5, SURVEY.md §8d
 CONV_FLOP_PER_POSITION = 2 * 25 * 256 * 2304   # one 3x3 256->256 conv on one 5x5 board
-TOWER_LAYERS = 40                              # net5: 20 residual blocks x 2 convs, fused into one launch
-FUSED_TOWER = os.environ.get("TZ_TOWER", "1") != "0"   # dominant kernel: the fused tower (default) or one conv
+TOWER_LAYERS = 40                              # net5: 20 residual blocks x 2 convs
+# dominant kernel by TZ_TOWER: 2 (default) = whole trunk + heads in one launch, 1 = residual tower in one launch,
+# 0 = one launch per conv.  Algorithmic FLOPs per position per launch (2 x MACs, real channel counts):
+FUSED_MODE = int(os.environ.get("TZ_TOWER", "2"))
+FLOP_PER_LAUNCH_POS = {0: CONV_FLOP_PER_POSITION,
+                       1: CONV_FLOP_PER_POSITION * TOWER_LAYERS,
+                       2: 2 * 25 * 256 * 32 * 9 + CONV_FLOP_PER_POSITION * TOWER_LAYERS + 2 * 25 * 123 * 2304 + 4 * 25 * 256}[FUSED_MODE]
+KERNEL_NAME = {0: "conv_mfma_kernel<5,8,2,9,false,0,true,8,1> (one 3x3 256->256 conv)",
+               1: "tower_mfma_kernel<5,8> (20 residual blocks = 40 3x3 256->256 convs, one persistent launch)",
+               2: "net_mfma_kernel<5,8,1> (game_repr + first conv + 20 residual blocks + policy conv + value/UBE heads, one persistent launch)"}[FUSED_MODE]
+FUSED_TOWER = FUSED_MODE >= 1
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 
 
@@ -183,17 +192,16 @@ def main():
         }
         if not args.no_profile and prof["conv_launches"]:
             per_launch_positions = (evals1 - evals0) / max(1.0, (sims1 - sims0) / args.games)
-            flop_per_launch = CONV_FLOP_PER_POSITION * per_launch_positions * (TOWER_LAYERS if FUSED_TOWER else 1)
+            flop_per_launch = FLOP_PER_LAUNCH_POS * per_launch_positions
             avg_ms = prof["conv_ms"] / prof["conv_launches"]
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
             traffic = None   # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/)
             tpath = os.path.join(ROOT, "profiles", "tower_pmc_traffic.json")
-            if FUSED_TOWER and args.games == GAMES and os.path.exists(tpath):
+            if FUSED_MODE == 2 and args.games == GAMES and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                               "kernel": ("tower_mfma_kernel<5,8> (20 residual blocks = 40 3x3 256->256 convs, one persistent launch)"
-                                          if FUSED_TOWER else "conv_mfma_kernel<5,8,2,9,false,0,true,8,1> (one 3x3 256->256 conv)"),
+                               "kernel": KERNEL_NAME,
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),

@@ -584,6 +584,294 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The whole trunk and its heads in ONE launch: game_repr + first conv (net5.rs:46-64), the residual tower, the policy
+// conv (net5.rs:75-87) and the value / UBE heads (net5.rs:89-120).  Same structure as tower_mfma_kernel; what
+// enters is the packed game states, what leaves is the policy tensor (fp32), value and UBE.  The block input of the
+// first conv are the planes built in LDS planes 0..kc_in-1; the policy conv and the heads read the tower's last
+// output from the LDS image.
+struct NetArgs {
+    const tz_state* states;
+    const int32_t* game_index;
+    const int32_t* count_dev;
+    int count_host;
+    const uint16_t* w_in;   // [9][kc_in][16][64][8]
+    const float* bias_in;   // [256]
+    int cin_real, kc_in;
+    const uint16_t* w;      // tower layers back to back
+    const float* bias;      // [nlayers][256]
+    int nlayers;
+    const uint16_t* w_pol;  // [9][8][8*RNP][64][8]
+    const float* bias_pol;  // [pol_stride]
+    float* policy_out;      // [rows][pol_stride]
+    int pol_stride;
+    const float* heads;     // heads_kernel layout
+    float* value;
+    float* ube;
+};
+
+// 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
+// weight fragments two k-steps ahead through a 4-slot ring (see tower_mfma_kernel)
+template <int NB, int RT, int RNX, int ROWS, int ZROW, int PLANE, typename ET, typename WL>
+__device__ __forceinline__ void k_loop_256(const unsigned char* lds, int lr, int q, f32x4 (&acc)[RT][RNX], WL wl) {
+    typedef typename Elem<ET>::x8 ex8;
+    constexpr int TAPS = 9, LAYOUT = 1;
+    ex8 bq[4][RNX];
+#pragma unroll
+    for (int j = 0; j < RNX; j++) {
+        bq[0][j] = wl(0, 0, j);
+        bq[1][j] = wl(0, 1, j);
+    }
+    int abase[RT];
+    {
+        int lr_t = lr;
+        asm volatile("" : "+v"(lr_t));
+        tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr_t, q, ROWS, ZROW, abase);
+    }
+    ex8 av[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+    for (int tap = 0; tap < TAPS; tap++) {
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            if (kc + 2 < 8) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
+            } else if (tap + 1 < TAPS) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc == 7) {
+                int lr_t = lr;
+                asm volatile("" : "+v"(lr_t));
+                tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
+            }
+            if (kc == 4) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    abase[rt] += 4 * PLANE;
+                    asm volatile("" : "+v"(abase[rt]));
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
+                if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
+                else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+            }
+        }
+    }
+}
+
+template <int NB, int P, int RNP, typename ET>
+__global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
+    typedef typename Elem<ET>::x8 ex8;
+    typedef typename Elem<ET>::x4 ex4;
+    constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
+    constexpr int PLANE = LROWS * LDS_ROWB;
+    constexpr int LAYER_FRAGS = TAPS * 8 * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* hscratch = reinterpret_cast<float*>(lds + 8 * PLANE);  // [2][RT*16] head pre-activations
+    const int count = a.count_dev ? *a.count_dev : a.count_host;
+    const int pos0 = blockIdx.x * P;
+    if (pos0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, lr = lane & 15;
+    const int valid_rows = min(ROWS, (count - pos0) * NN);
+    const size_t m0 = (size_t)pos0 * NN;
+    const int ct0 = wave * RN;
+    const int lane16 = lane * 16;
+
+    // ---- game_repr into planes 0..kc_in-1; zero rows of every plane
+    for (int row = tid; row < LROWS; row += NT) {
+        const bool ok = row < valid_rows;
+        const tz_state* s = nullptr;
+        int px = 0, fd = 0;
+        if (ok) {
+            const int pos = pos0 + row / NN;
+            px = row % NN;
+            s = a.states + (a.game_index ? a.game_index[pos] : pos);
+            fd = state_flat_diff<NB>(s);
+        }
+        for (int c8 = 0; c8 < a.kc_in * 4; c8++) {
+            ex8 v;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = c8 * 8 + k;
+                v[k] = (ET)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
+            }
+            *reinterpret_cast<ex8*>(lds + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = v;
+        }
+    }
+    for (int i = tid; i < 8 * 8 * 4; i += NT) {  // 8 planes x 8 zero rows x 4 pieces of 16 B
+        const int plane = i >> 5, zr = (i >> 2) & 7, pc = i & 3;
+        *reinterpret_cast<uint4*>(lds + plane * PLANE + (ZROW + zr) * LDS_ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
+    }
+    int obase[RN];
+#pragma unroll
+    for (int j = 0; j < RN; j++) obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
+
+    f32x4 acc[RT][RN];
+    // ---- first conv: cin_pad = 32*kc_in channels, 9*kc_in k-steps
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_in), 0, TAPS * a.kc_in * 16 * 1024, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias_in + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < TAPS; tap++) {
+            int abase[RT];
+            int lr_t = lr;
+            asm volatile("" : "+v"(lr_t));
+            tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr_t, q, ROWS, ZROW, abase);
+            for (int kc = 0; kc < a.kc_in; kc++) {
+                ex8 b[RN];
+#pragma unroll
+                for (int j = 0; j < RN; j++)
+                    b[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, ((tap * a.kc_in + kc) * 16 + ct0 + j) * 1024, 0));
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const ex8 av = *reinterpret_cast<const ex8*>(lds + abase[rt] + kc * PLANE);
+#pragma unroll
+                    for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(b[j], av, acc[rt][j]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RN; j++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                ex4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                *reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = pk;
+            }
+    }
+    // ---- residual tower
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    for (int layer = 0; layer < a.nlayers; layer++) {
+        if ((layer & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + layer * FILTERS + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
+            }
+        }
+        __syncthreads();
+        k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET>(lds, lr, q, acc, [&](int tap, int kc, int j) -> ex8 {
+            const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
+            return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
+        });
+        __syncthreads();
+        const bool to_second = (layer & 1) == 0;
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (to_second) b4 = *reinterpret_cast<const f32x4*>(a.bias + (layer + 1) * FILTERS + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
+                ex4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                if (to_second) {
+                    const ex4 xv = *slot;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
+                }
+                *slot = pk;
+            }
+        }
+    }
+    __syncthreads();  // the image now holds the tower's output
+    // ---- value / UBE heads: conv1x1(256->1)+bias, ReLU over the image rows, then Linear(nn->1) per board
+    {
+        const float* hw = a.heads;
+        float wv[4], wu[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            wv[k] = hw[lane * 4 + k];
+            wu[k] = hw[FILTERS + lane * 4 + k];
+        }
+        const float* lv = hw + 2 * FILTERS;
+        const float* lu = lv + NN;
+        const float bv = lu[NN], bu = lu[NN + 1], lbv = lu[NN + 2], lbu = lu[NN + 3];
+        const int hplane = lane >> 3, hpiece = (lane & 7) >> 1, hhalf = lane & 1;  // channels 4*lane .. 4*lane+3
+        for (int row = wave; row < ROWS; row += 8) {
+            const ex4 xv = *reinterpret_cast<const ex4*>(lds + hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8);
+            float dv = 0.f, du = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                dv += (float)xv[k] * wv[k];
+                du += (float)xv[k] * wu[k];
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                dv += __shfl_xor(dv, d);
+                du += __shfl_xor(du, d);
+            }
+            if (lane == 0) {
+                dv += bv;
+                du += bu;
+                hscratch[row] = dv > 0.f ? dv : 0.f;
+                hscratch[RT * 16 + row] = du > 0.f ? du : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int pos = wave; pos < P; pos += 8) {
+            if (pos0 + pos >= count) break;
+            float sv = 0.f, su = 0.f;
+            for (int px = lane; px < NN; px += 64) {
+                sv += hscratch[pos * NN + px] * lv[px];
+                su += hscratch[RT * 16 + pos * NN + px] * lu[px];
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                sv += __shfl_xor(sv, d);
+                su += __shfl_xor(su, d);
+            }
+            if (lane == 0) {
+                a.value[pos0 + pos] = tanhf(sv + lbv);
+                a.ube[pos0 + pos] = su + lbu;
+            }
+        }
+    }
+    // ---- policy conv: 16*RNP output channels per wave, fp32 out
+    {
+        const int ctp = wave * RNP;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_pol), 0, TAPS * 8 * 8 * RNP * 1024, 0x00020000);
+        f32x4 pacc[RT][RNP];
+#pragma unroll
+        for (int j = 0; j < RNP; j++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias_pol + (ctp + j) * 16 + q * 4);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) pacc[rt][j] = b4;
+        }
+        k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, lr, q, pacc, [&](int tap, int kc, int j) -> ex8 {
+            const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
+            return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
+        });
+#pragma unroll
+        for (int j = 0; j < RNP; j++) {
+            const int cbase = (ctp + j) * 16 + q * 4;
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int r = rt * 16 + lr;
+                if (r < valid_rows) *reinterpret_cast<f32x4*>(a.policy_out + (m0 + r) * a.pol_stride + cbase) = pacc[rt][j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 validation path: one thread per (row, output channel); weights [tap][cin][cout].
 template <int NB>
 __global__ void conv_f32_kernel(const float* in, const float* w, const float* bias, const float* residual, float* out,
@@ -1192,15 +1480,6 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     return conv_dispatch<__bf16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
 }
 
-bool tower_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("TZ_TOWER");
-        on = e ? atoi(e) : 1;
-    }
-    return on != 0;
-}
-
 template <int NB, int OPT = 0, typename ET = __bf16>
 int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
@@ -1235,6 +1514,67 @@ int tower_bf16(tz_net* net, const void* in, void* out, const int32_t* count_dev,
         case 6: return h ? launch_tower<6, 0, _Float16>(a, max_positions, st) : launch_tower<6>(a, max_positions, st);
     }
     return tz_fail(TZ_EINVAL, "tower: unsupported board size");
+}
+
+int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fused tower only; 0: one launch per conv
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("TZ_TOWER");
+        mode = e ? atoi(e) : 2;
+    }
+    return mode;
+}
+
+template <int NB, int RNP, typename ET>
+int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
+    constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
+    const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float);
+    auto kern = net_mfma_kernel<NB, P, RNP, ET>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((max_positions + P - 1) / P), dim3(512), smem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("net launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
+template <typename ET>
+int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t st) {
+    switch (net->n) {
+        case 3: return launch_net<3, 1, ET>(a, max_positions, st);
+        case 4: return launch_net<4, 1, ET>(a, max_positions, st);
+        case 5: return launch_net<5, 1, ET>(a, max_positions, st);
+        case 6: return launch_net<6, 2, ET>(a, max_positions, st);
+    }
+    return tz_fail(TZ_EINVAL, "net: unsupported board size");
+}
+
+int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const int32_t* count_dev, int count_host,
+              int max_positions, hipStream_t st) {
+    NetArgs a;
+    a.states = states;
+    a.game_index = gidx;
+    a.count_dev = count_dev;
+    a.count_host = count_host;
+    a.w_in = net->conv_in.w_mfma;
+    a.bias_in = net->conv_in.bias;
+    a.cin_real = net->conv_in.cin;
+    a.kc_in = net->conv_in.cin_pad / 32;
+    a.w = net->tower_w;
+    a.bias = net->tower_bias;
+    a.nlayers = 2 * net->blocks;
+    a.w_pol = net->policy.w_mfma;
+    a.bias_pol = net->policy.bias;
+    a.policy_out = net->policy_out;
+    a.pol_stride = net->pol_stride;
+    a.heads = net->heads;
+    a.value = net->value;
+    a.ube = net->ube;
+    if (net->precision == TZ_PREC_F16) return net_fused_et<_Float16>(net, a, max_positions, st);
+    return net_fused_et<__bf16>(net, a, max_positions, st);
 }
 
 int conv_f32(tz_net* net, const ConvW& L, const float* in, int in_stride, const int32_t* count_dev, int count_host,
@@ -1323,11 +1663,24 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     const bool need_planes = !bf || net->has_hash;
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
-    if (bf) {
+    if (bf && net->blocks > 0 && net->tower_w && net_fused_mode() == 2) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (net->profile) {
+            TZ_HIP(hipEventCreate(&e0));
+            TZ_HIP(hipEventCreate(&e1));
+            TZ_HIP(hipEventRecord(e0, st));
+        }
+        if ((rc = net_fused(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
+        if (net->profile) {
+            TZ_HIP(hipEventRecord(e1, st));
+            net->conv_events.push_back({e0, e1});
+            net->conv_launches += 1;
+        }
+    } else if (bf) {
         if ((rc = conv_bf16(net, net->conv_in, nullptr, states, gidx, count_dev, count_host, max_positions, nullptr, x, FILTERS,
                             true, false, true, st)))
             return rc;
-        if (net->blocks > 0 && net->tower_w && tower_enabled()) {
+        if (net->blocks > 0 && net->tower_w && net_fused_mode() >= 1) {
             // the residual tower as one persistent launch
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (net->profile) {
