@@ -481,11 +481,13 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
             }
         }
+        constexpr int PD = (OPT & 8) ? 3 : 2;  // weight prefetch distance in k-steps (slot = k-step & 3)
         if (layer == 0 || !(OPT & 1)) {
 #pragma unroll
             for (int j = 0; j < RN; j++) {
                 bq[0][j] = wload(layer, 0, 0, j);
                 bq[1][j] = wload(layer, 0, 1, j);
+                if (PD == 3) bq[2][j] = wload(layer, 0, 2, j);
             }
         }
         __syncthreads();  // the LDS image of this layer's input is complete
@@ -509,15 +511,15 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
         for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
             for (int kc = 0; kc < 8; kc++) {
-                if (kc + 2 < 8) {
+                if (kc + PD < 8) {
 #pragma unroll
-                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap, kc + 2, j);
+                    for (int j = 0; j < RN; j++) bq[(kc + PD) & 3][j] = wload(layer, tap, kc + PD, j);
                 } else if (tap + 1 < TAPS) {
 #pragma unroll
-                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap + 1, kc + 2 - 8, j);
+                    for (int j = 0; j < RN; j++) bq[(kc + PD) & 3][j] = wload(layer, tap + 1, kc + PD - 8, j);
                 } else if ((OPT & 1) && layer + 1 < a.nlayers) {  // next layer's first fragments ride under this layer's epilogue
 #pragma unroll
-                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer + 1, 0, kc + 2 - 8, j);
+                    for (int j = 0; j < RN; j++) bq[(kc + PD) & 3][j] = wload(layer + 1, 0, kc + PD - 8, j);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kc == 7) {
@@ -2027,6 +2029,7 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 1: r = launch_tower<5, 1>(a, positions, net->stream); break;
                 case 2: r = launch_tower<5, 2>(a, positions, net->stream); break;
                 case 4: r = launch_tower<5, 4>(a, positions, net->stream); break;
+                case 8: r = launch_tower<5, 8>(a, positions, net->stream); break;
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }

@@ -293,3 +293,10 @@ class OracleSearch:
         a, b = C.c_uint64(), C.c_uint64()
         self.lib.tzo_search_counters(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    # aliases so that drivers written against takzero_amd.api.BatchedMCTS run on the oracle unchanged
+    def gumbel_sequential_halving(self, betas, k, budget, gumbel):
+        return self.gumbel_sh(betas, k, budget, gumbel)
+
+    def restart_terminal_envs(self, choice):
+        return self.restart_terminal(choice)

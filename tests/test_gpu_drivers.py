@@ -140,3 +140,34 @@ def test_reanalyze_iteration(oracle, tmp_path):
     b0, b1 = RA.PositionBuffer(mcts, n, 4, 0, 2), RA.PositionBuffer(mcts, n, 4, 1, 2)
     full = RA.PositionBuffer(mcts, n, 4)
     assert b0.read_new(str(rpath)) + b1.read_new(str(rpath)) == full.read_new(str(rpath))
+
+
+def test_compete_matches_oracle(oracle):
+    """evaluation::compete (evaluation/src/main.rs:224-319): two nets, two trees per game, same Gumbel draws on both
+    engines -> identical game outcomes (every move of every game is the same)."""
+    A = require_gpu()
+    from takzero_amd import evaluation as E
+    from takzero_amd import weights as W
+    from test_gpu_engine import _agent_over
+
+    n, B = 4, 12
+    nets = []
+    for seed in (1, 2):
+        net = A.Net(arch=A.ARCH_TEST, n=n, precision=A.PREC_F16, blocks=1)
+        net.load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=seed))
+        nets.append(net)
+    games = random_positions(oracle, O, n, 4, B, 99, min_ply=2, max_ply=3)
+    res = []
+    for engine in ("gpu", "oracle"):
+        if engine == "gpu":
+            w = A.BatchedMCTS(B, n, 4, agent=nets[0], node_capacity=1 << 13)
+            b = A.BatchedMCTS(B, n, 4, agent=nets[1], node_capacity=1 << 13)
+            g = O.states_array(games)
+        else:
+            w = O.OracleSearch(oracle, B, n, 4, agent_kind=0, agent_fn=_agent_over(nets[0]))
+            b = O.OracleSearch(oracle, B, n, 4, agent_kind=0, agent_fn=_agent_over(nets[1]))
+            g = O.states_array(games)
+        ev = E.compete(w, b, g, 0.0, 0.0, np.random.default_rng(5), sampled_actions=4, search_budget=16, max_moves=40)
+        res.append((ev.wins, ev.losses, ev.draws, w.get_positions().tobytes(), b.get_positions().tobytes()))
+    assert res[0] == res[1]
+    assert sum(res[0][:3]) <= B
