@@ -71,8 +71,12 @@ def eval_to_f32(tag, bits):
 
 
 def _states(states):
-    arr = np.ascontiguousarray(states, dtype=STATE_DTYPE)
-    return arr.reshape(-1)
+    # field-wise copy into a zeroed buffer: numpy leaves the struct's tail padding uninitialised when it gathers
+    # records (fancy indexing), and positions are compared / hashed as raw bytes
+    arr = np.asarray(states, dtype=STATE_DTYPE).reshape(-1)
+    out = np.zeros(arr.shape[0], STATE_DTYPE)
+    out[...] = arr
+    return out
 
 
 class Net:

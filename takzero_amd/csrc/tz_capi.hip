@@ -242,6 +242,8 @@ int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int ha
         return tz_fail(TZ_ENOMEM, "tz_search_create: device allocation failed (lower node_capacity or batch)");
     }
     TZ_HIP(hipMemsetAsync(d.bank, 0, batch, s->stream));
+    TZ_HIP(hipMemsetAsync(d.env, 0, (size_t)batch * sizeof(tz_state), s->stream));
+    TZ_HIP(hipMemsetAsync(d.leaf_env, 0, (size_t)batch * sizeof(tz_state), s->stream));
     TZ_HIP(hipMemsetAsync(d.betas, 0, batch * sizeof(float), s->stream));
     TZ_HIP(hipMemsetAsync(d.start_node, 0, batch * sizeof(int32_t), s->stream));
     TZ_HIP(hipMemsetAsync(d.counters, 0, 2 * sizeof(unsigned long long), s->stream));

@@ -322,10 +322,9 @@ __device__ __forceinline__ void default_reserves(int n, int& stones, int& caps) 
 // lane 0 only
 template <int N>
 __device__ void write_opening(tz_state* e, int half_komi, int choice, bool with_moves) {
-    for (int i = 0; i < TZ_MAX_SQUARES; i++) {
-        e->colors[i] = 0;
-        e->height[i] = 0;
-        e->top[i] = 0;
+    {   // every byte, including the struct's tail padding: positions are compared and hashed as raw bytes
+        uint32_t* wds = reinterpret_cast<uint32_t*>(e);
+        for (int i = 0; i < (int)(sizeof(tz_state) / 4); i++) wds[i] = 0;
     }
     int st, cp;
     default_reserves(N, st, cp);
