@@ -121,8 +121,18 @@ def main():
 
         dist = dist_mod
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.zeros(1, device="cuda:%d" % local_rank)
+                dist.all_reduce(probe)          # fail here, not in the timed region, if RCCL cannot form the ring
+                torch.cuda.synchronize()
+            except Exception as e:              # the shards are independent: the target exchange can run over gloo
+                sys.stderr.write("rank %d: RCCL unavailable (%r), exchanging targets over gloo\n" % (rank, e))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
     import takzero_amd.api as A
@@ -205,7 +215,7 @@ def main():
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
-                                            "tower_convs": prof["conv_ms"] / max(1, prof["steps"]),
+                                            "dominant_kernel": prof["conv_ms"] / max(1, prof["steps"]),
                                             "wall": 1000.0 * dt / max(1.0, (sims1 - sims0) / args.games)}
             out["net_flops_frac_of_peak"] = (evals / dt_max) * FLOP_PER_POSITION / (world * PEAK_BF16_TFLOPS * 1e12)
         if world == 1 and not args.no_cpu_baseline:
