@@ -102,7 +102,21 @@ class Net:
             pass
 
     def load(self, path):
-        check(self.lib.tz_net_load_weights(self.h, str(path).encode()))
+        """Network::load (network/mod.rs:24-28).  `.ot` = the reference's LibTorch archive (converted on the host,
+        takzero_amd.ot); anything else = the flat .tzw container.  SimHash nets also pick up `bitvec.bin` from the
+        same directory (net6_simhash.rs:173-190)."""
+        path = str(path)
+        if path.endswith(".ot"):
+            import os
+
+            from . import ot
+
+            self.load_tensors(ot.load_ot(path))
+            bits = os.path.join(os.path.dirname(path), "bitvec.bin")
+            if self.arch in (ARCH_NET4_SIMHASH, ARCH_NET6_SIMHASH) and os.path.exists(bits):
+                self.load_bitset(bits)
+            return self
+        check(self.lib.tz_net_load_weights(self.h, path.encode()))
         return self
 
     def load_tensors(self, tensors):

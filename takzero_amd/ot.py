@@ -1,0 +1,78 @@
+"""Reading the reference's model files.  `learn` writes `model_latest.ot` / `model_NNNNNNN.ot` with tch's
+VarStore::save (takzero/src/network/mod.rs:16-18): a LibTorch `torch::serialize::OutputArchive` holding one
+named tensor per variable, names = VarStore paths joined with '.'.  PyTorch reads that archive with
+torch.jit.load.
+
+Name quirk (residual.rs:50-55): both SmallBlocks of a ResidualBlock are created under the same
+path, so the second one's five variables collide with the first one's and tch renames them
+`<path>__<number of variables registered so far>`.  This module maps   <name> -> `.a.`   and
+<name>__K -> `.b.`   whatever K is, which gives the names takzero_amd.weights / tz_net_load_weights use."""
+import re
+
+import numpy as np
+
+_SUFFIX = re.compile(r"^(.*)__(\d+)$")
+_BLOCK = re.compile(r"^(core\.res_block_\d+)\.(.+)$")
+
+
+def read_ot(path):
+    """name -> fp32 ndarray for every tensor of a LibTorch archive (needs torch; host-side tooling only)."""
+    import torch
+
+    m = torch.jit.load(str(path), map_location="cpu")
+    out = {}
+    for k, v in list(m.named_parameters()) + list(m.named_buffers()):
+        out[k] = v.detach().to(torch.float32).numpy().copy()
+    return out
+
+
+def canonical_names(named):
+    """tch VarStore names -> the `.a.` / `.b.` spelling of takzero_amd.weights."""
+    out = {}
+    for name, arr in named.items():
+        m = _SUFFIX.match(name)
+        base, dup = (m.group(1), True) if m else (name, False)
+        b = _BLOCK.match(base)
+        if b:
+            out["%s.%s.%s" % (b.group(1), "b" if dup else "a", b.group(2))] = arr
+        elif dup:
+            raise ValueError("unexpected duplicated variable outside a residual block: %s" % name)
+        else:
+            out[base] = arr
+    return out
+
+
+def load_ot(path):
+    return canonical_names(read_ot(path))
+
+
+def tch_names(tensors):
+    """The inverse (what tch would name the variables when it builds the net: creation order of net5.rs /
+    net6_simhash.rs, duplicates suffixed with the number of variables registered so far).  Used to write test
+    archives; the reader above does not depend on the exact numbers."""
+    out, count = [], 0
+    seen = set()
+
+    def add(name, key):
+        nonlocal count
+        final = name if name not in seen else "%s__%d" % (name, count)
+        seen.add(final)
+        out.append((final, tensors[key]))
+        count += 1
+
+    def bn(path, key):
+        for v in ("running_mean", "running_var", "weight", "bias"):  # tch nn::batch_norm creation order
+            add("%s.%s" % (path, v), "%s.%s" % (key, v))
+
+    add("core.input_conv2d.weight", "core.input_conv2d.weight")
+    bn("core.batch_norm", "core.batch_norm")
+    b = 0
+    while "core.res_block_%d.a.conv2d.weight" % b in tensors:
+        for half in "ab":
+            add("core.res_block_%d.conv2d.weight" % b, "core.res_block_%d.%s.conv2d.weight" % (b, half))
+            bn("core.res_block_%d.batch_norm" % b, "core.res_block_%d.%s.batch_norm" % (b, half))
+        b += 1
+    rest = [k for k in tensors if not k.startswith("core.")]
+    for k in rest:
+        add(k, k)
+    return out
