@@ -28,6 +28,7 @@ struct tz_search {
     // ~60 launches per simulation would otherwise leave the GPU waiting for the host
     hipGraphExec_t graph[2] = {nullptr, nullptr};
     int warm[2] = {0, 0};
+    uint64_t graph_gen[2] = {0, 0};  // tz_net::weights_gen the graph was captured with
     bool use_graph = true;
     uint64_t sim_index = 0;
     // profiling
@@ -97,6 +98,11 @@ int one_simulation(tz_search* s, bool from_start) {
         s->warm[gi]++;
         return one_simulation_eager(s, from_start, sample);
     }
+    if (s->graph[gi] && s->net && s->graph_gen[gi] != s->net->weights_gen) {
+        // hot reload (selfplay/src/main.rs:107-110): the captured launches point at the old weights
+        (void)hipGraphExecDestroy(s->graph[gi]);
+        s->graph[gi] = nullptr;
+    }
     if (!s->graph[gi]) {
         hipGraph_t g = nullptr;
         TZ_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -110,6 +116,7 @@ int one_simulation(tz_search* s, bool from_start) {
         const hipError_t ei = hipGraphInstantiate(&s->graph[gi], g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (ei != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        s->graph_gen[gi] = s->net ? s->net->weights_gen : 0;
     }
     TZ_HIP(hipGraphLaunch(s->graph[gi], s->stream));
     return TZ_OK;

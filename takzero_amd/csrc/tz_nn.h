@@ -17,6 +17,7 @@ struct tz_net {
     int n = 0, nn = 0, arch = 0, device = 0, precision = 0, blocks = 0;
     int cin = 0, cin_pad = 0, pol_ch = 0, pol_stride = 0, ppt = 0;
     bool loaded = false, has_rnd = false, has_hash = false;
+    uint64_t weights_gen = 0;  // bumped by every successful load: captured graphs hold weight pointers
     ConvW conv_in, policy;
     std::vector<ConvW> res;  // 2 per block
     uint16_t* tower_w = nullptr;  // all residual-tower layers back to back (fused tower kernel)

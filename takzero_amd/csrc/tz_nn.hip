@@ -1871,7 +1871,7 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
         free_weights(W);
         return rc;  // old weights stay active (selfplay/src/main.rs:112-115)
     }
-    TZ_HIP(hipStreamSynchronize(net->stream));
+    TZ_HIP(hipDeviceSynchronize());  // searches run this net on their own streams; reloads are rare
     NetWeights old;
     old.conv_in = net->conv_in;
     old.policy = net->policy;
@@ -1901,6 +1901,7 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     net->simhash = W.simhash;
     free_weights(old);
     net->loaded = true;
+    net->weights_gen++;
     return TZ_OK;
 }
 

@@ -1,0 +1,150 @@
+"""The directory protocol of the reference's `selfplay` and `reanalyze` binaries, so that an unmodified `learn`
+process can sit on the other side of the same directory:
+
+  buffer_lengths.txt     "selfplay,reanalyze,sum" written by learn; we pause while our buffer is over the cap
+                         (selfplay/src/main.rs:90-105, 371-387; reanalyze/src/main.rs:78-91)
+  model_latest.ot        re-read before every move / iteration (selfplay/src/main.rs:107-121)
+  targets-selfplay.txt, replays.txt, targets-reanalyze.txt   appended (selfplay/src/main.rs:332-366,
+                         reanalyze/src/main.rs:230-243)
+
+With more than one rank each rank appends to its own files unless `gather` is set, in which case the targets are
+all-gathered (takzero_amd.selfplay.all_gather_targets) and rank 0 writes them."""
+import os
+import time
+
+import numpy as np
+
+from . import formats
+from .reanalyze import Reanalyze
+from .selfplay import SelfPlay, all_gather_targets
+
+MAX_SELFPLAY_BUFFER_LEN = 32_000   # selfplay/src/main.rs:43
+MAX_REANALYZE_BUFFER_LEN = 32_000  # reanalyze/src/main.rs:40
+MIN_POSITIONS = 4000 * 128 // 4    # reanalyze/src/main.rs:38
+
+
+def read_buffer_lengths(directory):
+    with open(os.path.join(directory, "buffer_lengths.txt")) as f:
+        return formats.parse_buffer_lengths(f.read())
+
+
+class ModelWatcher:
+    """Net::load(directory/model_latest.ot) before every search.  The reference re-reads the file every time;
+    we re-read it only when its (mtime, size) changed, which gives the same network."""
+
+    def __init__(self, net, directory, name="model_latest.ot"):
+        self.net, self.path, self.stamp, self.reloads = net, os.path.join(directory, name), None, 0
+
+    def refresh(self):
+        """True if a (new) model is loaded; raises OSError if the file is missing (caller retries)."""
+        st = os.stat(self.path)
+        stamp = (st.st_mtime_ns, st.st_size)
+        if stamp != self.stamp:
+            self.net.load(self.path)
+            self.stamp = stamp
+            self.reloads += 1
+            return True
+        return False
+
+
+def wait_until_needed(directory, which, cap, watcher, sleep=1.0, max_wait=None, log=None):
+    """The inner `loop` of both binaries: block while learn's buffer for `which` (0 selfplay, 1 reanalyze) is over
+    `cap`, then (re)load the model.  A model that cannot be parsed is kept as is for selfplay ("not retrying",
+    selfplay/src/main.rs:112-115) and retried for reanalyze (reanalyze/src/main.rs:98-101)."""
+    t0 = time.monotonic()
+
+    def expired():
+        return max_wait is not None and time.monotonic() - t0 > max_wait
+
+    while True:
+        try:
+            length = read_buffer_lengths(directory)[which]
+        except (OSError, ValueError) as err:
+            if log:
+                log("Could not read buffer lengths: %s" % err)
+            if expired():
+                raise TimeoutError("buffer_lengths.txt unreadable for %.0f s" % max_wait)
+            time.sleep(sleep)
+            continue
+        if length > cap:
+            if expired():
+                raise TimeoutError("buffer over its cap for %.0f s" % max_wait)
+            time.sleep(sleep)
+            continue
+        if watcher is None:
+            return
+        try:
+            watcher.refresh()
+            return
+        except OSError as err:  # missing file: "some other reason, retrying"
+            if log:
+                log("Cannot load model: %s, retrying." % err)
+            if expired():
+                raise TimeoutError("no model for %.0f s" % max_wait)
+            time.sleep(sleep)
+        except Exception as err:  # archive present but unreadable
+            if log:
+                log("Cannot load model (parse error): %s" % err)
+            if which == 0:
+                return
+            if expired():
+                raise
+            time.sleep(sleep)
+
+
+def append_lines(path, lines):
+    if not lines:
+        return
+    with open(path, "a") as f:  # OpenOptions::append(true).create(true)
+        f.write("".join(lines))
+
+
+def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, world=1, search="gumbel",
+                 sampled_actions=64, gather=False, watch_model=True, sleep=1.0, max_wait=None, log=None):
+    """selfplay::main (selfplay/src/main.rs:63-205) for `moves` outer iterations (None = forever)."""
+    n = mcts.n
+    sp = SelfPlay(mcts, sims_per_move, seed=seed, shard=rank, search=search, sampled_actions=sampled_actions)
+    watcher = ModelWatcher(mcts.agent, directory) if watch_model else None
+    suffix = "" if world == 1 or gather else "-rank%d" % rank
+    step = 0
+    while moves is None or step < moves:
+        wait_until_needed(directory, 0, MAX_SELFPLAY_BUFFER_LEN, watcher, sleep, max_wait, log)
+        targets, replays = sp.play_move()
+        if gather and world > 1:
+            targets = all_gather_targets(targets, n)
+        if not gather or rank == 0:
+            append_lines(os.path.join(directory, "targets-selfplay%s.txt" % suffix),
+                         [formats.format_target(n, *t) for t in targets])
+        append_lines(os.path.join(directory, "replays%s.txt" % ("" if world == 1 else "-rank%d" % rank)),
+                     [formats.format_replay(n, *r) for r in replays])
+        step += 1
+    return sp
+
+
+def run_reanalyze(directory, mcts, sims, iterations=None, seed=0, rank=0, world=1, search="gumbel",
+                  sampled_actions=64, min_positions=MIN_POSITIONS, watch_model=True, sleep=1.0, max_wait=None,
+                  log=None):
+    """reanalyze::main (reanalyze/src/main.rs:60-244) for `iterations` outer iterations (None = forever)."""
+    n = mcts.n
+    ra = Reanalyze(mcts, sims, seed=seed, rank=rank, world=world, search=search, sampled_actions=sampled_actions)
+    watcher = ModelWatcher(mcts.agent, directory) if watch_model else None
+    suffix = "" if world == 1 else "-rank%d" % rank
+    it = 0
+    t0 = time.monotonic()
+    while iterations is None or it < iterations:
+        wait_until_needed(directory, 1, MAX_REANALYZE_BUFFER_LEN, watcher, sleep, max_wait, log)
+        try:
+            ra.buffer.read_new(os.path.join(directory, "replays.txt"))
+        except OSError as err:
+            if log:
+                log("Cannot fill position buffer: %s" % err)
+        if len(ra.buffer.positions) < max(min_positions, mcts.batch):
+            if max_wait is not None and time.monotonic() - t0 > max_wait:
+                raise TimeoutError("not enough positions (%d)" % len(ra.buffer.positions))
+            time.sleep(sleep)  # the reference sleeps 60 s here (reanalyze/src/main.rs:135-142)
+            continue
+        targets = ra.iterate()
+        append_lines(os.path.join(directory, "targets-reanalyze%s.txt" % suffix),
+                     [formats.format_target(n, *t) for t in targets])
+        it += 1
+    return ra

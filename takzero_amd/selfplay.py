@@ -67,6 +67,10 @@ class SelfPlay:
         else:
             gumbel = self.rng.gumbel(size=(B, 512 if m.n < 6 else 1024)).astype(np.float32)
             actions = m.gumbel_sequential_halving(self.betas, self.k, self.sims, gumbel)  # :138-144
+            early = m.root_info()["ply"] < WEIGHTED_RANDOM_PLIES                           # :145-153
+            if early.any():
+                sampled = m.select_actions_in_selfplay(self.rng, WEIGHTED_RANDOM_PLIES)
+                actions = np.where(early, sampled, actions).astype(np.uint16)
         targets, replays = [], []
         if self.collect:
             self._record(actions)

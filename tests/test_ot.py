@@ -89,7 +89,7 @@ def test_net_load_ot_equals_load_tensors(ot_writer, tmp_path):
     oracle = O.load()
     w = W.init_weights(W.ARCH_NET6_SIMHASH, blocks=2, seed=5, trained_stats=True)
     path = _write_ot(ot_writer, tmp_path, w)
-    states = random_positions(oracle, O, 6, 4, 24, 3, max_ply=30)
+    states = O.states_array(random_positions(oracle, O, 6, 4, 24, 3, max_ply=30))
     a = tz.Net(arch=tz.ARCH_NET6_SIMHASH, blocks=2).load_tensors(w)
     b = tz.Net(arch=tz.ARCH_NET6_SIMHASH, blocks=2).load(path)
     ra, rb = a.forward_raw(states), b.forward_raw(states)
