@@ -222,6 +222,29 @@ int tz_search_sync(tz_search* s);
 int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_launches,
                       double* tree_ms, uint64_t* steps);
 
+/* ---------- Trainer: the `learn` step (learn/src/main.rs:376-423), SURVEY.md 8f row 4 ----------
+ * fp32 forward in training mode (BatchNorm batch statistics, running statistics updated with momentum 0.1),
+ * masked log-softmax cross entropy + value MSE + UBE MSE, backward, Adam(lr) as tch's nn::Adam::default().
+ * Tensors carry the VarStore names (`.a.` / `.b.` for the two SmallBlocks) and the reference's layouts.
+ * batch must be a multiple of 64 (the reference uses 128, learn/src/main.rs:43). */
+typedef struct tz_trainer tz_trainer;
+int tz_trainer_create(int board_n, int arch, int device_id, int blocks, int batch, float learning_rate, tz_trainer** out);
+int tz_trainer_destroy(tz_trainer* t);
+int tz_trainer_tensor_count(tz_trainer* t);
+int tz_trainer_tensor_info(tz_trainer* t, int i, char* name_out, int name_cap, uint64_t* count_out);
+/* what: 0 parameter / buffer, 1 gradient of the last step, 2 / 3 Adam first / second moment */
+int tz_trainer_set_tensor(tz_trainer* t, const char* name, int what, const float* data, uint64_t count);
+int tz_trainer_get_tensor(tz_trainer* t, const char* name, int what, float* out, uint64_t count);
+/* compute_loss_and_take_step: states[batch]; target_policy / mask [batch][tz_policy_size] (mask 1 = illegal,
+ * move_mask); target_value[batch]; target_ube[batch] variances (ln + clamp to [-10, ln 4] applied inside,
+ * learn/src/main.rs:360-363); train_ube = 0 in pre-training (:397-400); apply_step = 0 leaves the weights alone.
+ * losses_out[3] = policy, value, ube. */
+int tz_trainer_step(tz_trainer* t, const tz_state* states, const float* target_policy, const uint8_t* mask,
+                    const float* target_value, const float* target_ube, int train_ube, int apply_step,
+                    float* losses_out);
+/* outputs of the last step's forward_t(xs, true): policy [batch][policy_size], value [batch], ube [batch] (log) */
+int tz_trainer_outputs(tz_trainer* t, float* policy_out, float* value_out, float* ube_out);
+
 /* Diagnostic: evaluates on the device the f32 primitives the tree kernels must compute exactly as
  * the host does (op 0 exp, 1 ln, 2 sqrt, 3 a/b, 4 0.997^int(a), 5 (a+b)*a). */
 int tz_device_math(int op, const float* a, const float* b, float* out, int n);

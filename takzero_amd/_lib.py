@@ -30,6 +30,8 @@ SYMBOLS = [
     "tz_search_root_children", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
     "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync", "tz_search_pool_usage",
     "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_search_terminal_details", "tz_search_play_moves",
+    "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
+    "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
 ]
 
 _lib = None
@@ -96,6 +98,14 @@ def load():
     lib.tz_device_math.argtypes = [ci, vp, vp, vp, ci]
     lib.tz_debug_conv_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tz_debug_tower_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
+    lib.tz_trainer_create.argtypes = [ci, ci, ci, ci, ci, cf, C.POINTER(vp)]
+    lib.tz_trainer_destroy.argtypes = [vp]
+    lib.tz_trainer_tensor_count.argtypes = [vp]
+    lib.tz_trainer_tensor_info.argtypes = [vp, ci, C.c_char_p, ci, C.POINTER(C.c_uint64)]
+    lib.tz_trainer_set_tensor.argtypes = [vp, C.c_char_p, ci, vp, C.c_uint64]
+    lib.tz_trainer_get_tensor.argtypes = [vp, C.c_char_p, ci, vp, C.c_uint64]
+    lib.tz_trainer_step.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp]
+    lib.tz_trainer_outputs.argtypes = [vp, vp, vp, vp]
     _lib = lib
     return lib
 

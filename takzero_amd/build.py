@@ -14,6 +14,7 @@ UNITS = [
     ("tz_tree.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_capi.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_nn.hip", []),
+    ("tz_learn.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result"]

@@ -51,3 +51,4 @@ int tz_net_ensure_batch(tz_net* net, int batch);
 // If count_dev is non-null the number of valid slots is read on the device (<= max_positions).
 int tz_net_forward_device(tz_net* net, const tz_state* states_dev, const int32_t* game_index_dev,
                           const int32_t* count_dev, int count_host, int max_positions, hipStream_t st, NetOut* out);
+int tz_nn_encode_planes(int n, int cin, const tz_state* states_dev, int count, float* planes_dev, hipStream_t st);

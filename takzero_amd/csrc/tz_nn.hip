@@ -1621,6 +1621,21 @@ int encode(tz_net* net, const tz_state* states, const int32_t* gidx, const int32
 
 }  // namespace
 
+// game_to_tensor for `count` positions into NHWC fp32 planes (repr.rs:8-135); used by the trainer (tz_learn.hip)
+int tz_nn_encode_planes(int n, int cin, const tz_state* states_dev, int count, float* planes_dev, hipStream_t st) {
+    const int total = count * n * n, blocks = (total + 127) / 128;
+    switch (n) {
+        case 3: encode_kernel<3><<<blocks, 128, 0, st>>>(states_dev, nullptr, nullptr, count, cin, planes_dev); break;
+        case 4: encode_kernel<4><<<blocks, 128, 0, st>>>(states_dev, nullptr, nullptr, count, cin, planes_dev); break;
+        case 5: encode_kernel<5><<<blocks, 128, 0, st>>>(states_dev, nullptr, nullptr, count, cin, planes_dev); break;
+        case 6: encode_kernel<6><<<blocks, 128, 0, st>>>(states_dev, nullptr, nullptr, count, cin, planes_dev); break;
+        default: return tz_fail(TZ_EINVAL, "encode: unsupported board size");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("encode launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 int tz_net_ensure_batch(tz_net* net, int batch) {
     if (batch <= net->max_batch) return TZ_OK;

@@ -1,0 +1,125 @@
+"""The learn step against PyTorch autograd on the CPU (oracle/learn_torch.py): outputs in
+training mode, the three losses, every gradient, BatchNorm running statistics and the weights after Adam steps.
+fp32 on both sides; tolerances are stated next to each check."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_util import random_positions, require_gpu
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+
+def _batch(oracle, n, B, seed):
+    rng = np.random.default_rng(seed)
+    states = random_positions(oracle, O, n, 4, B, seed, max_ply=24)
+    planes = np.stack([O.game_repr(oracle, s) for s in states]).reshape(B, -1, n, n)
+    out = (3 + 4 * (2 ** n - 2)) * n * n
+    policy = np.zeros((B, out), np.float32)
+    mask = np.ones((B, out), np.uint8)
+    for i, s in enumerate(states):
+        mv = np.array(O.possible_moves(oracle, s), np.int64)
+        p = rng.random(len(mv)).astype(np.float32)
+        policy[i, mv] = p / p.sum() * (0.97 if i % 3 == 0 else 1.0)  # visit-count targets need not sum to one
+        mask[i, mv] = 0
+    value = rng.uniform(-1, 1, B).astype(np.float32)
+    ube = rng.uniform(1e-6, 5.0, B).astype(np.float32)  # some above MAXIMUM_VARIANCE, some tiny: both clamps
+    ube[0] = 1e-9
+    return O.states_array(states), planes, policy, mask, value, ube
+
+
+@pytest.mark.parametrize("n,blocks", [(4, 2), (5, 1)])
+def test_step_matches_torch_autograd(n, blocks):
+    import torch
+
+    import learn_torch as LT
+    A = require_gpu()
+    from takzero_amd import learn as L
+    from takzero_amd import weights as W
+
+    oracle = O.load()
+    B, lr = 64, 1e-4
+    w = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=3 + n, trained_stats=True)
+    tr = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=blocks, batch=B, lr=lr).load_tensors(w)
+    p = LT.make_params(w)
+    opt = LT.adam(p, lr)
+    torch.manual_seed(0)
+    for step, train_ube in enumerate((True, False, True)):
+        states, planes, policy, mask, value, ube = _batch(oracle, n, B, 100 + step)
+        got = tr.step(states, policy, mask, value, ube, train_ube=train_ube, apply=True)
+        grads = {k: tr.tensor(k, L.GRAD) for k in tr.names if "running_" not in k}
+        outs = tr.outputs()
+        opt.zero_grad(set_to_none=True)
+        want, wouts = LT.losses(p, torch.from_numpy(planes), torch.from_numpy(mask.astype(bool)), torch.from_numpy(policy),
+                                torch.from_numpy(value), torch.from_numpy(ube), blocks, train_ube)
+        (want[0] + want[1] + want[2]).backward()
+        # forward outputs in training mode: fp32 sums in a different order -> 2e-4 absolute on O(1) logits
+        for g, t_ in zip(outs, wouts):
+            assert np.allclose(g, t_.detach().numpy(), atol=2e-4, rtol=1e-4)
+        for g, t_ in zip(got, want):
+            assert abs(g - float(t_)) <= 1e-5 + 1e-4 * abs(float(t_)), (step, got, [float(x) for x in want])
+        # gradients: within 1e-3 of the tensor's largest gradient on the first step (identical weights on both sides);
+        # later steps start from weights that differ by up to 2 lr wherever a gradient was ~0 (Adam moves those by
+        # +-lr on either side of zero), so the comparison there only guards against gross errors
+        gtol = 1e-3 if step == 0 else 3e-2
+        for k, g in grads.items():
+            tg = p[k].grad
+            if tg is None:
+                assert k.startswith("ube.") and not train_ube
+                continue
+            tg = tg.numpy().reshape(g.shape)
+            scale = float(np.abs(tg).max()) + 1e-12
+            assert float(np.abs(g - tg).max()) <= gtol * scale + 1e-7, (step, k, float(np.abs(g - tg).max()), scale)
+        opt.step()
+        # weights after the step: Adam moves every weight by about lr, in the direction of its gradient's sign, so
+        # agreement to a small fraction of lr means the same update was applied; gradients near zero may differ more
+        for k in tr.names:
+            a, b = tr.tensor(k), p[k].detach().numpy().reshape(tr.tensor(k).shape)
+            diff = np.abs(a - b)
+            if "running_" in k:
+                assert float(diff.max()) <= 1e-5 + 1e-4 * float(np.abs(b).max()), (step, k)
+            else:
+                assert float(np.quantile(diff, 0.99)) <= 0.05 * lr, (step, k, float(np.quantile(diff, 0.99)))
+                assert float(diff.max()) <= 2.5 * lr * (step + 1), (step, k, float(diff.max()))
+    # the UBE head was stepped twice, everything else three times (torch.optim.Adam keeps a step count per tensor)
+    assert float(np.abs(tr.tensor("ube.linear.weight") - w["ube.linear.weight"]).max()) <= 2 * lr * 1.01
+
+
+def test_trained_weights_feed_the_inference_net():
+    """learn -> model file -> selfplay: the trainer's tensors load into the inference Net, and with BatchNorm running
+    statistics in place the fp32 inference path reproduces an eval-mode forward of the same weights."""
+    A = require_gpu()
+    from takzero_amd import learn as L
+    from takzero_amd import weights as W
+
+    oracle = O.load()
+    n, blocks, B = 4, 1, 64
+    w = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=9, trained_stats=True)
+    tr = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=blocks, batch=B).load_tensors(w)
+    states, planes, policy, mask, value, ube = _batch(oracle, n, B, 7)
+    first = tr.step(states, policy, mask, value, ube)
+    for _ in range(20):
+        last = tr.step(states, policy, mask, value, ube)
+    assert sum(last[:2]) < sum(first[:2]), (first, last)  # the same batch 20 times: the loss goes down
+    trained = tr.tensors()
+    assert set(trained) == set(w)
+    net = A.Net(arch=A.ARCH_TEST, n=n, precision=A.PREC_F32, blocks=blocks).load_tensors(trained)
+    pol, val, _ = net.forward_raw(states)
+    assert np.isfinite(pol).all() and np.isfinite(val).all()
+
+
+def test_trainer_rejects_bad_arguments():
+    A = require_gpu()
+    from takzero_amd import learn as L
+
+    with pytest.raises(A.TakzeroError):
+        L.Trainer(arch=A.ARCH_TEST, n=4, blocks=1, batch=100)  # not a multiple of 64
+    tr = L.Trainer(arch=A.ARCH_TEST, n=4, blocks=1, batch=64)
+    with pytest.raises(ValueError):
+        tr.load_tensors({})
+    with pytest.raises(ValueError):
+        tr.step(np.zeros(3, A.STATE_DTYPE), np.zeros((3, 4)), np.zeros((3, 4)), np.zeros(3), np.zeros(3))
