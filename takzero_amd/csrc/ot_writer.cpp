@@ -1,6 +1,7 @@
-// Test tool: writes a genuine LibTorch archive exactly as tch's VarStore::save does (torch-sys at_save_multi:
-// OutputArchive::write(name, tensor) for every variable, then save_to).  Input: a text manifest of
-// "<archive name> <n dims> <dims...> <raw f32 file>" lines prepared by the test.
+// ot_writer — writes a LibTorch archive exactly as tch's VarStore::save does (network/mod.rs:16-18 -> torch-sys
+// at_save_multi: OutputArchive::write(name, tensor) for every variable, then save_to), so that the reference's
+// Net::load reads models trained here.  Host tool of takzero_amd.ot.save_ot; input: a text manifest of
+// "<archive name> <n dims> <dims...> <raw f32 file>" lines.  Built on demand with g++ against the torch wheel.
 #include <torch/torch.h>
 
 #include <fstream>

@@ -108,3 +108,200 @@ class Trainer:
         pol, val, ube = np.zeros((B, out), np.float32), np.zeros(B, np.float32), np.zeros(B, np.float32)
         check(self.lib.tz_trainer_outputs(self.h, pol.ctypes.data, val.ctypes.data, ube.ctypes.data))
         return pol, val, ube
+
+
+# ---------------------------------------------------------------------------------------------
+# learn::main (learn/src/main.rs:99-289): replay buffers with forced uses, back-pressure file, model files
+STEPS_PER_SAVE = 100               # :44
+STEPS_PER_CHECKPOINT = 50_000      # :45
+INITIAL_RANDOM_TARGETS = BATCH_SIZE * 2_000  # :49
+PRE_TRAINING_STEPS = 1_000         # :50
+STEPS_BEFORE_REANALYZE = 5000      # :54
+MIN_SELFPLAY_BUFFER_LEN = 10_000   # :55
+MIN_REANALYZE_BUFFER_LEN = 2_000   # :57
+SELFPLAY_TARGET_FORCED_USES = 4    # :59
+REANALYZE_TARGET_FORCED_USES = 4   # :60
+
+
+class TargetBuffer:
+    """Vec<TargetWithContext> fed from an append-only targets file (fill_buffer_with_targets, :291-319)."""
+
+    def __init__(self, n, half_komi, forced_uses):
+        self.n, self.half_komi, self.forced_uses = n, half_komi, forced_uses
+        self.items = []   # [target, remaining uses, model steps when read]
+        self.seek = 0
+
+    def __len__(self):
+        return len(self.items)
+
+    def fill(self, path, model_steps):
+        from . import formats
+
+        with open(path, "rb") as f:
+            f.seek(self.seek)
+            data = f.read()
+        end = data.rfind(b"\n")
+        if end < 0:
+            return 0
+        self.seek += end + 1
+        added = 0
+        for raw in data[:end].split(b"\n"):
+            try:
+                target = formats.parse_target(raw.decode() + "\n", self.n, self.half_komi)
+            except Exception:
+                continue  # filter_map(|line| line.parse().ok())
+            self.items.append([target, self.forced_uses, model_steps])
+            added += 1
+        return added
+
+    def take(self, rng, count):
+        """shuffle, drain the last `count` (create_batch, :493-499)."""
+        rng.shuffle(self.items)
+        batch = self.items[len(self.items) - count:]
+        del self.items[len(self.items) - count:]
+        return batch
+
+    def give_back(self, batch):
+        for item in batch:  # TargetWithContext::reuse
+            if item[1] > 1:
+                item[1] -= 1
+                self.items.append(item)
+
+
+def model_path_with_most_steps(directory):
+    """get_model_path_with_most_steps (:272-289): model_<steps>.ot with the largest number."""
+    import os
+
+    best = None
+    for name in os.listdir(directory):
+        stem, ext = os.path.splitext(name)
+        if ext != ".ot" or "_" not in stem:
+            continue
+        tail = stem.split("_", 1)[1]
+        if tail.isdigit() and (best is None or int(tail) > best[0]):
+            best = (int(tail), os.path.join(directory, name))
+    return best
+
+
+def create_batch(using_reanalyze, exploitation, reanalyze, rng, n, batch=BATCH_SIZE, augment=True):
+    """create_batch + create_input_and_target_tensors (:486-516, :330-374)."""
+    from . import augment as AU
+
+    if using_reanalyze:
+        a, b = exploitation.take(rng, batch // 2), reanalyze.take(rng, batch // 2)
+        items = a + b
+    else:
+        a, b = exploitation.take(rng, batch), []
+        items = a
+    targets = [AU.augment_target(it[0], rng, n) if augment else it[0] for it in items]
+    exploitation.give_back(a)
+    reanalyze.give_back(b)
+    return target_tensors(targets, n)
+
+
+def pre_training(trainer, mcts, rng_seed, directory=None, initial_targets=INITIAL_RANDOM_TARGETS,
+                 steps=PRE_TRAINING_STEPS, log=None):
+    """pre_training (:425-484): uniformly random games from the openings, uniform policy targets, discounted game
+    result as value, UBE target 4 - eps; the UBE head is not trained.  `mcts`: a BatchedMCTS with the Dummy agent."""
+    import os
+
+    from . import formats
+    from .selfplay import SelfPlay
+
+    sp = SelfPlay(mcts, 0, seed=rng_seed, search="random")
+    rng = np.random.default_rng([rng_seed, 11])
+    buffer = []
+    while len(buffer) < initial_targets:
+        targets, _ = sp.play_move()
+        buffer.extend(targets)
+    order = rng.permutation(len(buffer))
+    buffer = [buffer[i] for i in order]
+    if directory is not None:
+        with open(os.path.join(directory, "targets-initial.txt"), "w") as f:
+            f.write("".join(formats.format_target(mcts.n, *t) for t in buffer))
+    B, losses = trainer.batch, []
+    from . import augment as AU
+
+    for s in range(min(steps, len(buffer) // B)):
+        chunk = [AU.augment_target(t, rng, mcts.n) for t in buffer[s * B:(s + 1) * B]]
+        losses.append(trainer.step(*target_tensors(chunk, mcts.n), train_ube=False))
+        if log and s % 100 == 0:
+            log("pre-training step %d: %r" % (s, losses[-1]))
+    return losses
+
+
+def save_model(trainer, path, hash_net=None):
+    """Network::save (network/mod.rs:16-18; net6_simhash.rs:152-171 also writes bitvec.bin beside the model)."""
+    import os
+
+    from . import ot
+
+    ot.save_ot(path, trainer.tensors())
+    if hash_net is not None:
+        hash_net.save_bitset(os.path.join(os.path.dirname(str(path)), "bitvec.bin"))
+
+
+def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mcts=None, hash_net=None,
+              min_selfplay=MIN_SELFPLAY_BUFFER_LEN, min_reanalyze=MIN_REANALYZE_BUFFER_LEN,
+              steps_before_reanalyze=STEPS_BEFORE_REANALYZE, steps_per_save=STEPS_PER_SAVE,
+              steps_per_checkpoint=STEPS_PER_CHECKPOINT, pre_training_steps=PRE_TRAINING_STEPS,
+              initial_targets=INITIAL_RANDOM_TARGETS, read_interval=10.0, sleep=30.0, max_wait=None, log=None):
+    """learn::main (:99-270).  `trainer` must already hold initial weights (Net::new) unless the directory has a
+    model_<steps>.ot to resume from.  Returns the number of training steps the model has seen."""
+    import os
+    import time
+
+    from . import formats, ot
+
+    n, rng = trainer.n, np.random.default_rng([seed, 5])
+    resume = model_path_with_most_steps(directory)
+    if resume is not None:
+        starting_steps = resume[0]
+        trainer.load_tensors(ot.load_ot(resume[1]))
+    else:
+        starting_steps = 0
+        save_model(trainer, os.path.join(directory, "model_0000000.ot"), hash_net)
+        if pre_train_mcts is not None and pre_training_steps > 0:
+            pre_training(trainer, pre_train_mcts, seed, directory, initial_targets, pre_training_steps, log)
+            starting_steps += pre_training_steps
+            save_model(trainer, os.path.join(directory, "model_%07d.ot" % starting_steps), hash_net)
+    save_model(trainer, os.path.join(directory, "model_latest.ot"), hash_net)
+    exploitation = TargetBuffer(n, half_komi, SELFPLAY_TARGET_FORCED_USES)
+    reanalyze = TargetBuffer(n, half_komi, REANALYZE_TARGET_FORCED_USES)
+    last_loaded = -1e18
+    model_steps = starting_steps
+    done = 0
+    t0 = time.monotonic()
+    while steps is None or done < steps:
+        model_steps += 1
+        using_reanalyze = model_steps >= steps_before_reanalyze
+        while True:
+            if time.monotonic() - last_loaded >= read_interval:
+                for buf, name, use in ((exploitation, "targets-selfplay.txt", True),
+                                       (reanalyze, "targets-reanalyze.txt", using_reanalyze)):
+                    if use:
+                        try:
+                            buf.fill(os.path.join(directory, name), model_steps)
+                        except OSError as err:
+                            if log:
+                                log("Cannot read %s: %s" % (name, err))
+                last_loaded = time.monotonic()
+                with open(os.path.join(directory, "buffer_lengths.txt"), "w") as f:
+                    f.write(formats.format_buffer_lengths(len(exploitation), len(reanalyze)))
+            if len(exploitation) >= min_selfplay and (not using_reanalyze or len(reanalyze) >= min_reanalyze):
+                break
+            if max_wait is not None and time.monotonic() - t0 > max_wait:
+                raise TimeoutError("not enough targets (%d selfplay, %d reanalyze)" % (len(exploitation), len(reanalyze)))
+            time.sleep(sleep)
+        tensors = create_batch(using_reanalyze, exploitation, reanalyze, rng, n, trainer.batch)
+        losses = trainer.step(*tensors, train_ube=True)
+        if hash_net is not None:
+            hash_net.hash_indices(tensors[0], update=True)  # net.update_counts(&tensors.input), :418
+        if log:
+            log("step %d: loss_policy %.5f loss_value %.5f loss_ube %.5f" % ((model_steps,) + losses))
+        if model_steps % steps_per_save == 0:
+            save_model(trainer, os.path.join(directory, "model_latest.ot"), hash_net)
+        if model_steps % steps_per_checkpoint == 0:
+            save_model(trainer, os.path.join(directory, "model_%07d.ot" % model_steps), hash_net)
+        done += 1
+    return model_steps

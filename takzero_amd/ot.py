@@ -7,9 +7,15 @@ Name quirk (residual.rs:50-55): both SmallBlocks of a ResidualBlo
 path, so the second one's five variables collide with the first one's and tch renames them
 `<path>__<number of variables registered so far>`.  This module maps   <name> -> `.a.`   and
 <name>__K -> `.b.`   whatever K is, which gives the names takzero_amd.weights / tz_net_load_weights use."""
+import os
 import re
+import subprocess
+import tempfile
 
 import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WRITER = os.path.join(HERE, "ot_writer")
 
 _SUFFIX = re.compile(r"^(.*)__(\d+)$")
 _BLOCK = re.compile(r"^(core\.res_block_\d+)\.(.+)$")
@@ -76,3 +82,39 @@ def tch_names(tensors):
     for k in rest:
         add(k, k)
     return out
+
+
+def build_writer(force=False):
+    """g++ takzero_amd/csrc/ot_writer.cpp against the torch wheel's LibTorch -> takzero_amd/ot_writer."""
+    src = os.path.join(HERE, "csrc", "ot_writer.cpp")
+    if not force and os.path.exists(WRITER) and os.path.getmtime(WRITER) >= os.path.getmtime(src):
+        return WRITER
+    import torch
+
+    tdir = os.path.dirname(torch.__file__)
+    cmd = ["g++", "-std=c++17", "-O1", src, "-o", WRITER, "-I" + os.path.join(tdir, "include"),
+           "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-L" + os.path.join(tdir, "lib"),
+           "-ltorch", "-ltorch_cpu", "-lc10", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("cannot build the LibTorch archive writer: " + r.stderr[-500:])
+    return WRITER
+
+
+def save_ot(path, tensors):
+    """Network::save (network/mod.rs:16-18): `tensors` by canonical (`.a.` / `.b.`) name -> LibTorch archive with
+    tch's variable names.  Written to a temporary file and renamed, so a reader never sees half a model."""
+    exe = build_writer()
+    path = str(path)
+    with tempfile.TemporaryDirectory() as tmp:
+        manifest = os.path.join(tmp, "manifest.txt")
+        with open(manifest, "w") as mf:
+            for i, (name, arr) in enumerate(tch_names(tensors)):
+                raw = os.path.join(tmp, "t%d.bin" % i)
+                a = np.ascontiguousarray(arr, np.float32)
+                a.tofile(raw)
+                mf.write("%s %d %s %s\n" % (name, a.ndim, " ".join(str(d) for d in a.shape), raw))
+        part = path + ".part"
+        subprocess.check_call([exe, manifest, part])
+        os.replace(part, path)
+    return path

@@ -64,6 +64,13 @@ class SelfPlay:
             m.apply_noise(noise, NOISE_RATIO)               # :131
             m.simulate(self.betas, self.sims)               # :134-136
             actions = m.select_actions_in_selfplay(self.rng, WEIGHTED_RANDOM_PLIES)  # batched.rs:165-183
+        elif self.search == "random":
+            # uniformly random legal moves (learn's pre_training games, learn/src/main.rs:437-445): one simulation
+            # expands the roots, which lists the legal moves
+            m.simulate(self.betas, 1)
+            ch, info = m.root_children(), m.root_info()
+            j = np.minimum((self.rng.random(B) * info["n_children"]).astype(np.int64), info["n_children"] - 1)
+            actions = ch["move_idx"][np.arange(B), j].astype(np.uint16)
         else:
             gumbel = self.rng.gumbel(size=(B, 512 if m.n < 6 else 1024)).astype(np.float32)
             actions = m.gumbel_sequential_halving(self.betas, self.k, self.sims, gumbel)  # :138-144
@@ -92,11 +99,17 @@ class SelfPlay:
         if self.search == "puct":
             vis = ch["visits"].astype(np.float32)
             pol = vis / np.maximum(info["visit_count"].astype(np.float32), 1)[:, None]  # target.rs:151-164
+        elif self.search == "random":
+            pol = np.broadcast_to((np.float32(1.0) / np.maximum(info["n_children"], 1).astype(np.float32))[:, None],
+                                  ch["visits"].shape).copy()  # uniform policy, learn/src/main.rs:451-454
         else:
             lg = int(np.log2(self.k))
             visitations = (self.sims // lg // self.k) * (2 ** lg - 1)  # selfplay/src/main.rs:47-52
             pol = m.improved_policy(float(visitations), ch["visits"].shape[1])
-        ube = m.ube_target(BETA)
+        if self.search == "random":
+            ube = np.full(m.batch, np.float32(4.0) - np.finfo(np.float32).eps, np.float32)  # learn/src/main.rs:460
+        else:
+            ube = m.ube_target(BETA)
         stepped = ~((info["eval_tag"] != api.EVAL_VALUE) & (info["eval_bits"] == 0))  # batched.rs:137
         self.history.append(dict(states=states, moves=ch["move_idx"], pol=pol, ube=ube,
                                  nchild=info["n_children"].copy(), stepped=stepped, actions=np.array(actions)))

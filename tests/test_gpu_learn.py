@@ -123,3 +123,60 @@ def test_trainer_rejects_bad_arguments():
         tr.load_tensors({})
     with pytest.raises(ValueError):
         tr.step(np.zeros(3, A.STATE_DTYPE), np.zeros((3, 4)), np.zeros((3, 4)), np.zeros(3), np.zeros(3))
+
+
+def test_closed_loop_learn_writes_models_that_selfplay_reloads(tmp_path):
+    """learn::main at toy scale next to selfplay on one directory: pre-training on random games, model_*.ot written
+    in the reference's format, selfplay targets consumed with forced uses, buffer_lengths.txt written, and the
+    self-play side picking up model_latest.ot."""
+    A = require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import learn as L
+    from takzero_amd import ot
+    from takzero_amd import runner as R
+    from takzero_amd import weights as W
+
+    try:
+        ot.build_writer()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    d, n, blocks, B = str(tmp_path), 4, 1, 64
+    w = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=21)
+    trainer = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=blocks, batch=B).load_tensors(w)
+    dummy = A.BatchedMCTS(96, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 10)
+    # self-play side first: some targets with the initial weights
+    net = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(w)
+    mcts = A.BatchedMCTS(96, n, 4, agent=net, node_capacity=1 << 13)
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    R.run_selfplay(d, mcts, 16, moves=40, seed=2, search="gumbel", sampled_actions=4, watch_model=False, max_wait=5)
+    produced = sum(1 for _ in open(os.path.join(d, "targets-selfplay.txt")))
+    assert produced >= 2 * B
+    logs = []
+    steps = L.run_learn(d, trainer, steps=7, seed=1, pre_train_mcts=dummy, min_selfplay=B, steps_before_reanalyze=10 ** 9,
+                        steps_per_save=2, steps_per_checkpoint=4, pre_training_steps=5, initial_targets=5 * B,
+                        read_interval=0.0, sleep=0.01, max_wait=20, log=logs.append)
+    assert steps == 5 + 7  # saved at every second step, so model_latest.ot is the final state
+    names = sorted(os.listdir(d))
+    for want in ("model_0000000.ot", "model_0000005.ot", "model_0000008.ot", "model_latest.ot", "targets-initial.txt",
+                 "buffer_lengths.txt"):
+        assert want in names, names
+    sp_len, re_len = R.read_buffer_lengths(d)
+    assert re_len == 0 and 0 < sp_len <= produced
+    initial = open(os.path.join(d, "targets-initial.txt")).read().splitlines(keepends=True)
+    assert len(initial) >= 5 * B
+    st, mv, pol, value, ube = F.parse_target(initial[0], n, 4)
+    assert np.allclose(pol, 1.0 / len(mv)) and abs(ube - 4.0) < 1e-5 and abs(value) <= 1.0
+    # the weights moved, and the file on disk is what the trainer holds
+    latest = ot.load_ot(os.path.join(d, "model_latest.ot"))
+    held = trainer.tensors()
+    assert set(latest) == set(w)
+    assert np.array_equal(latest["policy.conv2d.weight"], held["policy.conv2d.weight"])
+    assert not np.array_equal(latest["policy.conv2d.weight"], w["policy.conv2d.weight"])
+    # resuming finds the checkpoint with the most steps
+    assert L.model_path_with_most_steps(d)[0] == 12
+    # the self-play side reloads it (ModelWatcher) and keeps playing
+    sp = R.run_selfplay(d, mcts, 16, moves=3, seed=3, search="gumbel", sampled_actions=4, watch_model=True, max_wait=5)
+    pol_a, _, _ = net.forward_raw(mcts.get_positions()[:8])
+    fresh = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(latest)
+    pol_b, _, _ = fresh.forward_raw(mcts.get_positions()[:8])
+    assert np.array_equal(pol_a, pol_b) and sp.moves_played == 3

@@ -1,27 +1,18 @@
 """The reference's `.ot` model files (tch VarStore::save = LibTorch OutputArchive): a real archive is written with
 LibTorch's C++ API under tch's variable names (incl. the `__K` suffix of the second SmallBlock) and read back."""
-import os
-import subprocess
-
 import numpy as np
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def ot_writer(tmp_path_factory):
-    import torch
+def ot_writer():
+    from takzero_amd import ot
 
-    tdir = os.path.dirname(torch.__file__)
-    exe = str(tmp_path_factory.mktemp("ot") / "tzw_to_ot")
-    cmd = ["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "tools", "tzw_to_ot.cpp"), "-o", exe,
-           "-I" + os.path.join(tdir, "include"), "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
-           "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-Wl,-rpath," + os.path.join(tdir, "lib")]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        pytest.skip("cannot build the LibTorch archive writer here: " + r.stderr[-300:])
-    return exe
+    try:
+        return ot.build_writer()
+    except RuntimeError as e:
+        pytest.skip(str(e))
 
 
 def test_ot_round_trip_through_libtorch(ot_writer, tmp_path):
@@ -29,19 +20,12 @@ def test_ot_round_trip_through_libtorch(ot_writer, tmp_path):
     from takzero_amd import weights as W
 
     w = W.init_weights(W.ARCH_TEST, n=3, blocks=2, seed=11, trained_stats=True)
-    named = ot.tch_names(w)
-    names = [n for n, _ in named]
+    names = [n for n, _ in ot.tch_names(w)]
     # the second SmallBlock of every ResidualBlock collides with the first one's path and gets `__K`
     assert "core.res_block_0.conv2d.weight" in names and any(n.startswith("core.res_block_0.conv2d.weight__") for n in names)
     assert len(set(names)) == len(names) == len(w)
-    manifest = tmp_path / "manifest.txt"
-    with open(manifest, "w") as mf:
-        for i, (name, arr) in enumerate(named):
-            raw = tmp_path / ("t%d.bin" % i)
-            np.ascontiguousarray(arr, np.float32).tofile(raw)
-            mf.write("%s %d %s %s\n" % (name, arr.ndim, " ".join(str(d) for d in arr.shape), raw))
-    path = tmp_path / "model_latest.ot"
-    subprocess.check_call([ot_writer, str(manifest), str(path)])
+    path = ot.save_ot(tmp_path / "model_latest.ot", w)
+    assert not (tmp_path / "model_latest.ot.part").exists()
     back = ot.load_ot(path)
     assert set(back) == set(w)
     for k in w:
@@ -62,20 +46,6 @@ def test_canonical_names_do_not_depend_on_the_suffix_number():
         ot.canonical_names({"policy.conv2d.bias__3": a})
 
 
-def _write_ot(ot_writer, tmp_path, w):
-    from takzero_amd import ot
-
-    manifest = tmp_path / "manifest.txt"
-    with open(manifest, "w") as mf:
-        for i, (name, arr) in enumerate(ot.tch_names(w)):
-            raw = tmp_path / ("t%d.bin" % i)
-            np.ascontiguousarray(arr, np.float32).tofile(raw)
-            mf.write("%s %d %s %s\n" % (name, arr.ndim, " ".join(str(d) for d in arr.shape), raw))
-    path = tmp_path / "model_latest.ot"
-    subprocess.check_call([ot_writer, str(manifest), str(path)])
-    return path
-
-
 @pytest.mark.gpu
 def test_net_load_ot_equals_load_tensors(ot_writer, tmp_path):
     """Network::load (network/mod.rs:24-28) on a LibTorch archive gives the same network as the flat container."""
@@ -88,7 +58,9 @@ def test_net_load_ot_equals_load_tensors(ot_writer, tmp_path):
     require_gpu()
     oracle = O.load()
     w = W.init_weights(W.ARCH_NET6_SIMHASH, blocks=2, seed=5, trained_stats=True)
-    path = _write_ot(ot_writer, tmp_path, w)
+    from takzero_amd import ot
+
+    path = ot.save_ot(tmp_path / "model_latest.ot", w)
     states = O.states_array(random_positions(oracle, O, 6, 4, 24, 3, max_ply=30))
     a = tz.Net(arch=tz.ARCH_NET6_SIMHASH, blocks=2).load_tensors(w)
     b = tz.Net(arch=tz.ARCH_NET6_SIMHASH, blocks=2).load(path)
