@@ -31,40 +31,43 @@ constexpr float MAXIMUM_VARIANCE = 4.0f;      // net5.rs:23
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
-// C[M][N] = (accumulate ? C : 0) + A x B (+ bias[n]).  M, N multiples of 64, K multiple of 16.
+// C[M][N] = (accumulate ? C : 0) + A x B (+ bias[n]).  M, N multiples of 64, K multiple of 32.
 // AT = false: A(m,k) = A[m*lda + k];  AT = true: A(m,k) = A[k*lda + m].   B(k,n) = B[k*ldb + n].
-// 4 waves per workgroup, each owns a 32x32 quadrant of the 64x64 tile; the next k-slab is fetched into
-// registers while the MFMAs of the current one run.
+// One 64x64 tile per workgroup of 8 waves = two groups of 4: group g multiplies the k-slabs 2i+g (16 deep), each
+// of its waves owning a 32x32 quadrant, so every SIMD has two waves to interleave; the two partial tiles are added
+// through LDS at the end (fixed order: deterministic).  Slabs are double buffered in LDS (one barrier per step) and
+// the next pair is fetched into registers while the MFMAs of the current one run.
 template <bool AT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const float* __restrict__ bias, int K,
                                                        int lda, int ldb, int ldc, int accumulate) {
-    __shared__ float As[16][68];
-    __shared__ float Bs[16][68];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ float As[2][2][16][68];  // [buffer][group][k][m]
+    __shared__ float Bs[2][2][16][68];
+    const int g = threadIdx.x >> 8, t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
     const size_t m0 = (size_t)blockIdx.x * 64, n0 = (size_t)blockIdx.y * 64;
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
     const int ak = AT ? (t >> 4) : (t & 3) * 4, am = AT ? (t & 15) * 4 : (t >> 2);
     const int bk = t >> 4, bn = (t & 15) * 4;
-    const float* ap = AT ? A + (size_t)ak * lda + m0 + am : A + (m0 + am) * lda + ak;
-    const float* bp = B + (size_t)bk * ldb + n0 + bn;
-    const size_t astep = AT ? (size_t)16 * lda : 16, bstep = (size_t)16 * ldb;
+    const float* ap = AT ? A + (size_t)(16 * g + ak) * lda + m0 + am : A + (m0 + am) * lda + 16 * g + ak;
+    const float* bp = B + (size_t)(16 * g + bk) * ldb + n0 + bn;
+    const size_t astep = AT ? (size_t)32 * lda : 32, bstep = (size_t)32 * ldb;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
     float4 ra = *(const float4*)ap, rb = *(const float4*)bp;
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += 32, buf ^= 1) {
         if (AT) {
-            *(float4*)&As[ak][am] = ra;
+            *(float4*)&As[buf][g][ak][am] = ra;
         } else {
-            As[ak + 0][am] = ra.x;
-            As[ak + 1][am] = ra.y;
-            As[ak + 2][am] = ra.z;
-            As[ak + 3][am] = ra.w;
+            As[buf][g][ak + 0][am] = ra.x;
+            As[buf][g][ak + 1][am] = ra.y;
+            As[buf][g][ak + 2][am] = ra.z;
+            As[buf][g][ak + 3][am] = ra.w;
         }
-        *(float4*)&Bs[bk][bn] = rb;
+        *(float4*)&Bs[buf][g][bk][bn] = rb;
         __syncthreads();
-        if (k0 + 16 < K) {
+        if (k0 + 32 < K) {
             ap += astep;
             bp += bstep;
             ra = *(const float4*)ap;
@@ -72,18 +75,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+            const float a = As[buf][g][kk + (lane >> 5)][wm + (lane & 31)];
+            const float b = Bs[buf][g][kk + (lane >> 5)][wn + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();
+    float* red = &As[0][0][0][0];  // 64 x 64 partial tile of group 1
+    if (g == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[(wm + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 64 + wn + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    if (g == 1) return;
     const size_t n = n0 + wn + (lane & 31);
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const size_t m = m0 + wm + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        float v = acc[r] + bv;
+        const int ml = wm + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        const size_t m = m0 + ml;
+        float v = acc[r] + red[ml * 64 + wn + (lane & 31)] + bv;
         if (accumulate) v += C[m * ldc + n];
         C[m * ldc + n] = v;
     }
@@ -400,13 +411,20 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(const float* __restric
     if (t == 0) loss_p[b] = red[0];
 }
 
-// column sums of a [M][ld] matrix (bias gradient of the policy conv)
-__global__ void column_sum_kernel(const float* __restrict__ x, int M, int ld, int count, float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
+// column sums of a [M][ld] matrix (bias gradient of the policy conv): one workgroup per 32 columns, 8 row lanes
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ x, int M, int ld, int count,
+                                                         float* __restrict__ out) {
+    __shared__ double part[8][32];
+    const int j = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
     double s = 0.0;
-    for (int m = 0; m < M; m++) s += x[(size_t)m * ld + j];
-    out[j] = (float)s;
+    if (j < count)
+        for (int m = r; m < M; m += 8) s += x[(size_t)m * ld + j];
+    part[r][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (r == 0 && j < count) {
+        for (int i = 1; i < 8; i++) s += part[i][threadIdx.x];
+        out[j] = (float)s;
+    }
 }
 
 __global__ void losses_kernel(const float* lp, const float* lv, const float* lu, int batch, float* out) {
@@ -546,12 +564,12 @@ int launch_check(const char* what) {
 
 int gemm(tz_trainer* t, bool at, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
          int ldb, int ldc, bool accumulate) {
-    if (M % 64 || N % 64 || K % 16 || lda % 4 || ldb % 4) return tz_fail(TZ_EINVAL, "trainer gemm: unaligned shape");
+    if (M % 64 || N % 64 || K % 32 || lda % 4 || ldb % 4) return tz_fail(TZ_EINVAL, "trainer gemm: unaligned shape");
     const dim3 grid(M / 64, N / 64);
     if (at)
-        gemm_f32_kernel<true><<<grid, 256, 0, t->stream>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
+        gemm_f32_kernel<true><<<grid, 512, 0, t->stream>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
     else
-        gemm_f32_kernel<false><<<grid, 256, 0, t->stream>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
+        gemm_f32_kernel<false><<<grid, 512, 0, t->stream>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
     return launch_check("gemm_f32");
 }
 
@@ -640,7 +658,7 @@ int backward(tz_trainer* t, int train_ube) {
     if ((rc = gemm(t, true, t->col, t->dpol, gp(t, "policy.conv2d.weight"), nullptr, 9 * FILTERS, t->np, M, 9 * FILTERS, t->np,
                    t->np, false)))
         return rc;
-    column_sum_kernel<<<(t->np + 63) / 64, 64, 0, t->stream>>>(t->dpol, M, t->np, t->np, gp(t, "policy.conv2d.bias"));
+    column_sum_kernel<<<(t->np + 31) / 32, 256, 0, t->stream>>>(t->dpol, M, t->np, t->np, gp(t, "policy.conv2d.bias"));
     if ((rc = launch_check("policy bias gradient"))) return rc;
     if ((rc = conv_dgrad(t, t->dpol, t->np, pp(t, "policy.conv2d.weight"), t->np, t->dA, true))) return rc;
     // trunk, last layer first.  `da` = gradient w.r.t. a[l]; three [M][256] buffers rotate between the roles

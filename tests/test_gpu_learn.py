@@ -57,15 +57,14 @@ def test_step_matches_torch_autograd(n, blocks):
         want, wouts = LT.losses(p, torch.from_numpy(planes), torch.from_numpy(mask.astype(bool)), torch.from_numpy(policy),
                                 torch.from_numpy(value), torch.from_numpy(ube), blocks, train_ube)
         (want[0] + want[1] + want[2]).backward()
-        # forward outputs in training mode: fp32 sums in a different order -> 2e-4 absolute on O(1) logits
+        # identical weights on both sides (see the re-synchronisation below), only the fp32 summation order differs
+        # (measured: 2e-6 on the outputs, 2e-6 relative on the gradients)
+        otol, ltol, gtol = 2e-5, 1e-5, 1e-4
         for g, t_ in zip(outs, wouts):
-            assert np.allclose(g, t_.detach().numpy(), atol=2e-4, rtol=1e-4)
+            assert np.allclose(g, t_.detach().numpy(), atol=otol, rtol=0)
         for g, t_ in zip(got, want):
-            assert abs(g - float(t_)) <= 1e-5 + 1e-4 * abs(float(t_)), (step, got, [float(x) for x in want])
-        # gradients: within 1e-3 of the tensor's largest gradient on the first step (identical weights on both sides);
-        # later steps start from weights that differ by up to 2 lr wherever a gradient was ~0 (Adam moves those by
-        # +-lr on either side of zero), so the comparison there only guards against gross errors
-        gtol = 1e-3 if step == 0 else 3e-2
+            assert abs(g - float(t_.detach())) <= ltol * (1 + abs(float(t_.detach()))), (step, got, [float(x.detach()) for x in want])
+        # gradients: error relative to the tensor's largest gradient
         for k, g in grads.items():
             tg = p[k].grad
             if tg is None:
@@ -84,7 +83,10 @@ def test_step_matches_torch_autograd(n, blocks):
                 assert float(diff.max()) <= 1e-5 + 1e-4 * float(np.abs(b).max()), (step, k)
             else:
                 assert float(np.quantile(diff, 0.99)) <= 0.05 * lr, (step, k, float(np.quantile(diff, 0.99)))
-                assert float(diff.max()) <= 2.5 * lr * (step + 1), (step, k, float(diff.max()))
+                assert float(diff.max()) <= 2.5 * lr, (step, k, float(diff.max()))
+            # a weight whose gradient is ~0 is moved by +-lr on either side of zero; copying the trainer's weights over
+            # keeps that from compounding, while torch's Adam state (step counts, both moments) stays its own
+            p[k].data.copy_(torch.from_numpy(a.reshape(p[k].shape)))
     # the UBE head was stepped twice, everything else three times (torch.optim.Adam keeps a step count per tensor)
     assert float(np.abs(tr.tensor("ube.linear.weight") - w["ube.linear.weight"]).max()) <= 2 * lr * 1.01
 

@@ -1,0 +1,38 @@
+"""Prints how far the learn step is from PyTorch autograd (outputs, losses, per-tensor gradient error)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import learn_torch as LT  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import takzero_amd.api as A  # noqa: E402
+from takzero_amd import learn as L  # noqa: E402
+from takzero_amd import weights as W  # noqa: E402
+from test_gpu_learn import _batch  # noqa: E402
+
+n, blocks, B = int(sys.argv[1]) if len(sys.argv) > 1 else 4, int(sys.argv[2]) if len(sys.argv) > 2 else 2, 64
+oracle = O.load()
+w = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=3 + n, trained_stats=True)
+tr = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=blocks, batch=B).load_tensors(w)
+p = LT.make_params(w)
+states, planes, policy, mask, value, ube = _batch(oracle, n, B, 100)
+got = tr.step(states, policy, mask, value, ube, train_ube=True, apply=False)
+want, wouts = LT.losses(p, torch.from_numpy(planes), torch.from_numpy(mask.astype(bool)), torch.from_numpy(policy),
+                        torch.from_numpy(value), torch.from_numpy(ube), blocks, True)
+(want[0] + want[1] + want[2]).backward()
+for name, g, t_ in zip(("policy", "value", "ube"), tr.outputs(), wouts):
+    t_ = t_.detach().numpy()
+    print("out %-8s max|x| %.3f  max diff %.3e" % (name, np.abs(t_).max(), np.abs(g - t_).max()))
+print("losses", got, [float(x.detach()) for x in want])
+worst = []
+for k in tr.names:
+    if "running_" in k:
+        continue
+    g, tg = tr.tensor(k, L.GRAD), p[k].grad.numpy()
+    worst.append((float(np.abs(g - tg.reshape(g.shape)).max() / (np.abs(tg).max() + 1e-12)), k))
+for r, k in sorted(worst, reverse=True)[:6]:
+    print("grad rel err %.3e  %s" % (r, k))
