@@ -24,7 +24,7 @@ namespace {
 constexpr int FILTERS = 256;
 constexpr float BN_EPS = 1e-5f;       // tch BatchNormConfig::default
 constexpr float BN_MOMENTUM = 0.1f;   // tch BatchNormConfig::default
-constexpr int SPLITS = 16;            // row splits of the per-channel reductions
+constexpr int SPLITS = 64;            // row splits of the per-channel reductions (8 x 64 workgroups)
 constexpr float MINIMUM_UBE_TARGET = -10.0f;  // learn/src/main.rs:47
 constexpr float MAXIMUM_VARIANCE = 4.0f;      // net5.rs:23
 
