@@ -1,4 +1,5 @@
-"""Prints how far the learn step is from PyTorch autograd (outputs, losses, per-tensor gradient error)."""
+"""Checker script (test infrastructure): prints how far the learn step is from PyTorch autograd (outputs, losses,
+per-tensor gradient error).  `python tests/learn_check.py [n] [blocks]` on a GPU box."""
 import os
 import sys
 

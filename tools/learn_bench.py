@@ -1,6 +1,6 @@
 """Times the learn step at the reference's configuration: net5, 20 blocks, batch 128
-(learn/src/main.rs:43).  `python tools/learn_bench.py [steps] [batch] [--cpu]`; --cpu also times the PyTorch fp32
-CPU restatement (oracle/learn_torch.py) on the host cores for a few steps."""
+(learn/src/main.rs:43).  `python tools/learn_bench.py [steps] [batch]`.  The CPU figure quoted beside it comes from
+tests/learn_cpu_time.py (the PyTorch fp32 restatement is test infrastructure and is not imported here)."""
 import json
 import os
 import sys
@@ -40,30 +40,6 @@ def main():
     flop = 3 * 1.1975e9 * B  # forward + data gradient + weight gradient of every conv / linear (RND is not trained)
     line = {"metric": "learn steps/s", "value": 1.0 / dt, "ms_per_step": dt * 1e3, "batch": B, "positions_per_s": B / dt,
             "tflops": flop / dt / 1e12, "losses": losses, "dtype": "f32"}
-    if "--cpu" in sys.argv:
-        import torch
-
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import learn_torch as LT
-        import oracle_lib as O
-
-        oracle = O.load()
-        planes = np.stack([O.game_repr(oracle, O.TzState.from_buffer_copy(s.tobytes())) for s in tensors[0]]).reshape(B, -1, n, n)
-        p = LT.make_params(w)
-        opt = LT.adam(p, 1e-4)
-        tt = [torch.from_numpy(planes), torch.from_numpy(tensors[2].astype(bool)), torch.from_numpy(tensors[1]),
-              torch.from_numpy(tensors[3]), torch.from_numpy(tensors[4])]
-        times = []
-        for i in range(4):
-            t1 = time.perf_counter()
-            opt.zero_grad(set_to_none=True)
-            ls, _ = LT.losses(p, *tt, 20, True)
-            (ls[0] + ls[1] + ls[2]).backward()
-            opt.step()
-            times.append(time.perf_counter() - t1)
-        line["cpu_ms_per_step"] = min(times[1:]) * 1e3
-        line["cpu_threads"] = torch.get_num_threads()
     print(json.dumps(line))
 
 
