@@ -245,7 +245,8 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
               min_selfplay=MIN_SELFPLAY_BUFFER_LEN, min_reanalyze=MIN_REANALYZE_BUFFER_LEN,
               steps_before_reanalyze=STEPS_BEFORE_REANALYZE, steps_per_save=STEPS_PER_SAVE,
               steps_per_checkpoint=STEPS_PER_CHECKPOINT, pre_training_steps=PRE_TRAINING_STEPS,
-              initial_targets=INITIAL_RANDOM_TARGETS, read_interval=10.0, sleep=30.0, max_wait=None, log=None):
+              initial_targets=INITIAL_RANDOM_TARGETS, restart_targets=None, read_interval=10.0, sleep=30.0,
+              max_wait=None, log=None):
     """learn::main (:99-270).  `trainer` must already hold initial weights (Net::new) unless the directory has a
     model_<steps>.ot to resume from.  Returns the number of training steps the model has seen."""
     import os
@@ -261,6 +262,25 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
     else:
         starting_steps = 0
         save_model(trainer, os.path.join(directory, "model_0000000.ot"), hash_net)
+    if restart_targets is not None:
+        # --restart-targets (:126-147): one pass over a saved target file, UBE head not trained
+        from . import augment as AU
+
+        with open(restart_targets) as f:
+            saved = []
+            for line in f:
+                try:
+                    saved.append(formats.parse_target(line, n, half_komi))
+                except Exception:
+                    continue
+        rng.shuffle(saved)
+        B = trainer.batch
+        for s in range(len(saved) // B):
+            chunk = [AU.augment_target(t, rng, n) for t in saved[s * B:(s + 1) * B]]
+            trainer.step(*target_tensors(chunk, n), train_ube=False)
+            starting_steps += 1
+        save_model(trainer, os.path.join(directory, "model_%07d.ot" % starting_steps), hash_net)
+    elif resume is None:
         if pre_train_mcts is not None and pre_training_steps > 0:
             pre_training(trainer, pre_train_mcts, seed, directory, initial_targets, pre_training_steps, log)
             starting_steps += pre_training_steps
@@ -274,7 +294,7 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
     t0 = time.monotonic()
     while steps is None or done < steps:
         model_steps += 1
-        using_reanalyze = model_steps >= steps_before_reanalyze
+        using_reanalyze = restart_targets is not None or model_steps >= steps_before_reanalyze
         while True:
             if time.monotonic() - last_loaded >= read_interval:
                 for buf, name, use in ((exploitation, "targets-selfplay.txt", True),

@@ -47,6 +47,65 @@ class ModelWatcher:
         return False
 
 
+class BroadcastModelWatcher(ModelWatcher):
+    """Weights reload for one process per GPU: rank 0 watches the file; when it changed, its tensors
+    go to every rank as one flat fp32 broadcast (RCCL on the GPU box, gloo in the CPU tests) and each rank loads them
+    into its own device copy.  Every rank calls refresh() once per move, so the two collectives stay matched."""
+
+    def __init__(self, net, directory, rank, name="model_latest.ot", device=None):
+        super().__init__(net, directory, name)
+        self.rank, self.device, self.layout = rank, device, None
+
+    def refresh(self):
+        import torch
+        import torch.distributed as dist
+
+        from . import ot
+
+        tensors, changed, err = None, 0, None
+        if self.rank == 0:
+            try:
+                st = os.stat(self.path)
+                stamp = (st.st_mtime_ns, st.st_size)
+                if stamp != self.stamp:
+                    tensors = ot.load_ot(self.path) if self.path.endswith(".ot") else None
+                    if tensors is None:
+                        from . import weights
+
+                        tensors = weights.load_tzw(self.path)
+                    self.stamp, changed = stamp, 1
+            except Exception as e:   # the other ranks must not be left waiting in the collective
+                err, changed = e, -1
+        dev = self.device if self.device is not None else "cpu"
+        flag = torch.tensor([changed], dtype=torch.int64, device=dev)
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) < 0:
+            raise err if err is not None else OSError("rank 0 could not read the model")
+        if int(flag.item()) == 0:
+            return False
+        if self.rank == 0:
+            names = sorted(tensors)
+            meta = [(k, tuple(tensors[k].shape)) for k in names]
+            flat = torch.from_numpy(np.concatenate([np.ascontiguousarray(tensors[k], np.float32).ravel() for k in names]))
+        else:
+            meta, flat = None, None
+        box = [meta]
+        dist.broadcast_object_list(box, src=0)
+        meta = box[0]
+        total = sum(int(np.prod(shape)) if shape else 1 for _, shape in meta)
+        buf = flat.to(dev) if self.rank == 0 else torch.empty(total, dtype=torch.float32, device=dev)
+        dist.broadcast(buf, src=0)
+        host = buf.cpu().numpy()
+        out, off = {}, 0
+        for k, shape in meta:
+            cnt = int(np.prod(shape)) if shape else 1
+            out[k] = host[off:off + cnt].reshape(shape).copy()
+            off += cnt
+        self.net.load_tensors(out)
+        self.reloads += 1
+        return True
+
+
 def wait_until_needed(directory, which, cap, watcher, sleep=1.0, max_wait=None, log=None):
     """The inner `loop` of both binaries: block while learn's buffer for `which` (0 selfplay, 1 reanalyze) is over
     `cap`, then (re)load the model.  A model that cannot be parsed is kept as is for selfplay ("not retrying",
@@ -100,11 +159,23 @@ def append_lines(path, lines):
 
 
 def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, world=1, search="gumbel",
-                 sampled_actions=64, gather=False, watch_model=True, sleep=1.0, max_wait=None, log=None):
-    """selfplay::main (selfplay/src/main.rs:63-205) for `moves` outer iterations (None = forever)."""
+                 sampled_actions=64, gather=False, watch_model=True, exploration=False, broadcast_model=False,
+                 sleep=1.0, max_wait=None, log=None):
+    """selfplay::main (selfplay/src/main.rs:63-205) for `moves` outer iterations (None = forever).
+    exploration = the cargo feature of that name: the first half of the games search with beta = 0.25 and the
+    openings of those games also go to replays-exploration.txt (:79-86, 279-290).
+    broadcast_model: only rank 0 reads model_latest.ot, the other ranks receive the tensors over torch.distributed."""
     n = mcts.n
-    sp = SelfPlay(mcts, sims_per_move, seed=seed, shard=rank, search=search, sampled_actions=sampled_actions)
-    watcher = ModelWatcher(mcts.agent, directory) if watch_model else None
+    betas = None
+    if exploration:
+        from .selfplay import BETA
+
+        betas = np.where(np.arange(mcts.batch) < mcts.batch // 2, BETA, 0.0).astype(np.float32)
+    sp = SelfPlay(mcts, sims_per_move, seed=seed, shard=rank, search=search, sampled_actions=sampled_actions, betas=betas)
+    watcher = None
+    if watch_model:
+        watcher = BroadcastModelWatcher(mcts.agent, directory, rank) if broadcast_model and world > 1 else \
+            ModelWatcher(mcts.agent, directory)
     suffix = "" if world == 1 or gather else "-rank%d" % rank
     step = 0
     while moves is None or step < moves:
@@ -115,8 +186,12 @@ def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, wor
         if not gather or rank == 0:
             append_lines(os.path.join(directory, "targets-selfplay%s.txt" % suffix),
                          [formats.format_target(n, *t) for t in targets])
-        append_lines(os.path.join(directory, "replays%s.txt" % ("" if world == 1 else "-rank%d" % rank)),
-                     [formats.format_replay(n, *r) for r in replays])
+        rsuffix = "" if world == 1 else "-rank%d" % rank
+        append_lines(os.path.join(directory, "replays%s.txt" % rsuffix), [formats.format_replay(n, *r) for r in replays])
+        if exploration:
+            append_lines(os.path.join(directory, "replays-exploration%s.txt" % rsuffix),
+                         [formats.format_replay(n, *r) for r in sp.exploration_replays])
+            sp.exploration_replays.clear()
         step += 1
     return sp
 

@@ -48,6 +48,7 @@ class SelfPlay:
         self.start_states = None
         self.moves_played = 0
         self.positions = 0
+        self.exploration_replays = []   # filled by _complete for games searched with beta > 0 (feature "exploration")
         mcts.new_openings(self.rng.integers(0, 16, mcts.batch))
         if self.collect:
             self.start_states = mcts.get_positions()
@@ -135,6 +136,8 @@ class SelfPlay:
                     targets.append((state.copy(), h["moves"][g, :k].copy(), h["pol"][g, :k].copy(),
                                     float(api.eval_to_f32(tag, ply)), float(h["ube"][g])))
             replays.append((self.start_states[g].copy(), acts[::-1], formats.result_string(reason[g], winner[g])))
+            if self.betas[g] > 0.0:     # the opening of an exploratory game (selfplay/src/main.rs:279-290)
+                self.exploration_replays.append((self.start_states[g].copy(), acts[::-1][:WEIGHTED_RANDOM_PLIES], None))
             self.game_start[g] = self.moves_played + 1
             self.start_states[g] = new_states[g]
         # drop history no running game refers to any more

@@ -182,3 +182,13 @@ def test_closed_loop_learn_writes_models_that_selfplay_reloads(tmp_path):
     fresh = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(latest)
     pol_b, _, _ = fresh.forward_raw(mcts.get_positions()[:8])
     assert np.array_equal(pol_a, pol_b) and sp.moves_played == 3
+
+    # --restart-targets (learn/src/main.rs:126-147): one pass over a saved target file in a fresh directory
+    d2 = os.path.join(d, "restart")
+    os.mkdir(d2)
+    fresh = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=blocks, batch=B).load_tensors(w)
+    steps2 = L.run_learn(d2, fresh, steps=0, seed=4, restart_targets=os.path.join(d, "targets-selfplay.txt"),
+                         read_interval=0.0, sleep=0.01, max_wait=5)
+    assert steps2 == produced // B and os.path.exists(os.path.join(d2, "model_%07d.ot" % steps2))
+    assert not np.array_equal(fresh.tensor("policy.conv2d.weight"), w["policy.conv2d.weight"])
+    assert np.array_equal(fresh.tensor("ube.linear.weight"), w["ube.linear.weight"])  # the UBE head is not trained there

@@ -134,3 +134,33 @@ def test_run_selfplay_and_reanalyze_on_a_directory(tmp_path):
     open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(R.MAX_SELFPLAY_BUFFER_LEN + 1, 0))
     with pytest.raises(TimeoutError):
         R.run_selfplay(d, mcts, 16, moves=1, watch_model=False, sleep=0.01, max_wait=0.1)
+
+
+@pytest.mark.gpu
+def test_exploration_feature_writes_truncated_replays_and_filters_targets(tmp_path):
+    """cargo feature "exploration" (selfplay/src/main.rs:79-86, 279-290, 318-320): the first half of the games search
+    with beta = 0.25; their openings (first 10 plies) also go to replays-exploration.txt and their positions only
+    become targets after ply 10."""
+    from gpu_util import require_gpu
+
+    A = require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import runner as R
+    from takzero_amd import weights as W
+
+    d, n, B = str(tmp_path), 4, 32
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    net = A.Net(arch=A.ARCH_TEST, n=n, blocks=1).load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=7))
+    mcts = A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 13)
+    sp = R.run_selfplay(d, mcts, 16, moves=60, seed=9, search="gumbel", sampled_actions=4, watch_model=False,
+                        exploration=True, max_wait=5)
+    assert list(sp.betas[:B // 2]) == [0.25] * (B // 2) and not sp.betas[B // 2:].any()
+    replays = [F.parse_replay(line, n, 4) for line in open(os.path.join(d, "replays.txt"))]
+    expl = [F.parse_replay(line, n, 4) for line in open(os.path.join(d, "replays-exploration.txt"))]
+    assert 0 < len(expl) < len(replays)
+    full = {(st.tobytes(), tuple(int(m) for m in mv[:10])) for st, mv in replays}
+    for st, mv in expl:
+        assert len(mv) <= 10 and (st.tobytes(), tuple(int(m) for m in mv)) in full
+    # exploitation games contribute every position, exploratory ones only those after ply 10: fewer targets than moves
+    n_targets = sum(1 for _ in open(os.path.join(d, "targets-selfplay.txt")))
+    assert n_targets < sum(len(mv) for _, mv in replays)
