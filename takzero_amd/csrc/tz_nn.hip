@@ -185,8 +185,8 @@ __device__ __forceinline__ void tap_bases_rc(int tap, int lr, int q, int rows, i
 // SINGLE: the whole reduction is one 256-channel slice (tower and policy convs): unrolled tile loader,
 // weight fragments prefetched two k-steps ahead.
 // NW = waves per workgroup; a workgroup covers NW*RN*16 output channels of P boards.
-template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false, int NW = 8, int LAYOUT = 1, typename ET = __bf16>
-__global__ __launch_bounds__(NW * 64, 2) void conv_mfma_kernel(ConvArgs a) {  // 2 waves per SIMD: <= 256 registers
+template <int NB, int P, int RN, int TAPS, bool FROM_STATE, int ABL = 0, bool SINGLE = false, int NW = 8, int LAYOUT = 1, typename ET = __bf16, int OCC = 2>
+__global__ __launch_bounds__(NW * 64, OCC) void conv_mfma_kernel(ConvArgs a) {  // OCC = 2 waves per SIMD: <= 256 registers
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
     constexpr int NT = NW * 64;
@@ -511,7 +511,8 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
         for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
             for (int kc = 0; kc < 8; kc++) {
-                if (kc + PD < 8) {
+                if constexpr (OPT & 32) {  // ablation: no weight stream
+                } else if (kc + PD < 8) {
 #pragma unroll
                     for (int j = 0; j < RN; j++) bq[(kc + PD) & 3][j] = wload(layer, tap, kc + PD, j);
                 } else if (tap + 1 < TAPS) {
@@ -539,7 +540,8 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 #pragma unroll
                     for (int j = 0; j < RN; j++)
                         acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
-                    if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * KSTEP);
+                    if constexpr (OPT & 16) {  // ablation: no activation-fragment reads
+                    } else if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * KSTEP);
                     else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
                 }
             }
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
         }
         __syncthreads();  // every wave is done reading the old image
         const bool to_second = (layer & 1) == 0;  // next conv is the block's second: it starts from x + bias
+        if constexpr (OPT & 64) continue;  // ablation: no epilogue
 #pragma unroll
         for (int j = 0; j < RN; j++) {
             f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1380,11 +1383,11 @@ int conv_cfg() {
     return cfg;
 }
 
-template <int NB, int P, int NW, int RN, int TAPS, bool FROM_STATE, bool SINGLE, int ABL = 0, int LAYOUT = 1, typename ET = __bf16>
+template <int NB, int P, int NW, int RN, int TAPS, bool FROM_STATE, bool SINGLE, int ABL = 0, int LAYOUT = 1, typename ET = __bf16, int OCC = 2>
 int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_t st) {
     constexpr int NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = LdsImg<LAYOUT>::bytes(LROWS);
-    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, ABL, SINGLE, NW, LAYOUT, ET>;
+    auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, ABL, SINGLE, NW, LAYOUT, ET, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1986,6 +1989,9 @@ int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, floa
                 case 20: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 0, 0>(a, positions, 1, net->stream); break;
                 case 21: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 1, 0>(a, positions, 1, net->stream); break;
                 case 23: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 3, 0>(a, positions, 1, net->stream); break;
+                case 30: rc = launch_conv<5, ppt_for(5), 4, 4, 9, false, true, 0, 1, __bf16, 1>(a, positions, 1, net->stream); break;
+                case 31: rc = launch_conv<5, ppt_for(5), 4, 4, 9, false, true, 1, 1, __bf16, 1>(a, positions, 1, net->stream); break;
+                case 33: rc = launch_conv<5, ppt_for(5), 4, 4, 9, false, true, 3, 1, __bf16, 1>(a, positions, 1, net->stream); break;
                 case 10: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 0>(a, positions, 1, net->stream); break;
                 case 11: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 1>(a, positions, 1, net->stream); break;
                 case 12: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 2>(a, positions, 1, net->stream); break;
@@ -2046,6 +2052,11 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 2: r = launch_tower<5, 2>(a, positions, net->stream); break;
                 case 4: r = launch_tower<5, 4>(a, positions, net->stream); break;
                 case 8: r = launch_tower<5, 8>(a, positions, net->stream); break;
+                case 16: r = launch_tower<5, 16>(a, positions, net->stream); break;
+                case 32: r = launch_tower<5, 32>(a, positions, net->stream); break;
+                case 48: r = launch_tower<5, 48>(a, positions, net->stream); break;
+                case 64: r = launch_tower<5, 64>(a, positions, net->stream); break;
+                case 112: r = launch_tower<5, 112>(a, positions, net->stream); break;
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }

@@ -74,8 +74,34 @@ def config5(games=4096, sims=1600, selfplay_moves=40, iterations=1):
     return out
 
 
+def gumbel(moves=3, games=4096, budget=768, k=64):
+    """What the reference's selfplay binary runs today (selfplay/src/main.rs:138-153): Gumbel sequential halving,
+    64 sampled actions, budget 768, on 5x5 / net5."""
+    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
+    mcts = A.BatchedMCTS(games, 5, 4, agent=net)
+    sp = SP.SelfPlay(mcts, budget, seed=0, search="gumbel", sampled_actions=k)
+    sp.play_move()
+    mcts.sync()
+    s0, e0 = mcts.counters()
+    t0 = time.perf_counter()
+    for _ in range(moves):
+        sp.play_move()
+    mcts.sync()
+    dt = time.perf_counter() - t0
+    s1, e1 = mcts.counters()
+    out = {"config": "5x5 Tak, %d games, Gumbel sequential halving k=%d budget=%d, net5" % (games, k, budget),
+           "sims_per_s": (s1 - s0) / dt, "nn_leaf_evals_per_s": (e1 - e0) / dt, "positions_per_s": games * moves / dt,
+           "s_per_move": dt / moves}
+    mcts.close()
+    net.close()
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["4", "5"]
+    if "gumbel" in which:
+        print(json.dumps(gumbel()), flush=True)
     if "4" in which:
         print(json.dumps(config4()), flush=True)
     if "5" in which:
