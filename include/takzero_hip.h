@@ -222,6 +222,17 @@ int tz_search_sync(tz_search* s);
 int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_launches,
                       double* tree_ms, uint64_t* steps);
 
+/* ---------- Target lines in bulk (impl Display / FromStr for Target, target.rs:56-73, 99-143) ----------
+ * "{tps};{value};{ube};{move}:{p},...\n" with Rust's `Display for f32`.  moves / policy are [count][amax]. */
+int tz_format_targets(int n, int count, const tz_state* states, const uint16_t* moves, const float* policy,
+                      const int32_t* nmoves, int amax, const float* value, const float* ube, char* out, uint64_t cap,
+                      uint64_t* written_out);
+/* parses the complete lines of text[0..len); unparsable lines are skipped (learn/src/main.rs:308);
+ * consumed_out = bytes to advance the file offset by */
+int tz_parse_targets(const char* text, uint64_t len, int n, int half_komi, int max_targets, int amax, tz_state* states,
+                     uint16_t* moves, float* policy, int32_t* nmoves, float* value, float* ube, int32_t* count_out,
+                     uint64_t* consumed_out, int32_t* skipped_out);
+
 /* ---------- Trainer: the `learn` step (learn/src/main.rs:376-423), SURVEY.md 8f row 4 ----------
  * fp32 forward in training mode (BatchNorm batch statistics, running statistics updated with momentum 0.1),
  * masked log-softmax cross entropy + value MSE + UBE MSE, backward, Adam(lr) as tch's nn::Adam::default().

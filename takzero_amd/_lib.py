@@ -32,6 +32,7 @@ SYMBOLS = [
     "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_search_terminal_details", "tz_search_play_moves",
     "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
     "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
+    "tz_format_targets", "tz_parse_targets",
 ]
 
 _lib = None
@@ -98,6 +99,9 @@ def load():
     lib.tz_device_math.argtypes = [ci, vp, vp, vp, ci]
     lib.tz_debug_conv_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tz_debug_tower_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
+    lib.tz_format_targets.argtypes = [ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.tz_parse_targets.argtypes = [vp, C.c_uint64, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     lib.tz_trainer_create.argtypes = [ci, ci, ci, ci, ci, cf, C.POINTER(vp)]
     lib.tz_trainer_destroy.argtypes = [vp]
     lib.tz_trainer_tensor_count.argtypes = [vp]

@@ -2,6 +2,8 @@
 // PTN <-> move_index, the formats the reference reads and writes through takparse
 // (call sites takzero/src/target.rs:56-73,99-143,215-268).  Pure host code,
 // no rules: legality lives in the device kernels.
+#include <charconv>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -218,6 +220,160 @@ int tz_move_from_ptn(int n, const char* ptn, uint16_t* move_index_out) {
     }
     if (sum != count || parts >= n) return tz_fail(TZ_EPARSE, "PTN: drops do not match the carry");
     *move_index_out = (uint16_t)((3 + slot * patterns + v - 1) * nn + sq);
+    return TZ_OK;
+}
+
+// ---- batched target lines (target.rs:56-73 Display, :99-143 FromStr): what selfplay / reanalyze append and learn
+// tails, thousands per move — formatted and parsed here rather than line by line in the host language.
+namespace {
+// Rust's `Display for f32`: shortest decimal that round-trips, never an exponent, "1" for 1.0, "NaN", "inf"
+void put_f32(std::string& o, float x) {
+    if (std::isnan(x)) {
+        o += "NaN";
+        return;
+    }
+    if (std::isinf(x)) {
+        o += x > 0 ? "inf" : "-inf";
+        return;
+    }
+    // shortest round-trip digits from the scientific form, then laid out positionally (Rust pads with zeros where
+    // to_chars' fixed form would print the exact binary value)
+    char buf[64];
+    const auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);
+    const char* p = buf;
+    if (*p == '-') {
+        o += '-';
+        p++;
+    }
+    char digits[32];
+    int nd = 0;
+    for (; p < r.ptr && *p != 'e'; p++)
+        if (*p != '.') digits[nd++] = *p;
+    int exp10 = 0;
+    if (p < r.ptr && *p == 'e') {
+        p++;
+        const bool neg = *p == '-';
+        if (*p == '-' || *p == '+') p++;
+        for (; p < r.ptr; p++) exp10 = exp10 * 10 + (*p - '0');
+        if (neg) exp10 = -exp10;
+    }
+    while (nd > 1 && digits[nd - 1] == '0') nd--;
+    if (exp10 < 0) {                 // 0.000ddd
+        o += "0.";
+        o.append((size_t)(-exp10 - 1), '0');
+        o.append(digits, nd);
+    } else if (exp10 + 1 >= nd) {    // ddd000
+        o.append(digits, nd);
+        o.append((size_t)(exp10 + 1 - nd), '0');
+    } else {                         // dd.ddd
+        o.append(digits, exp10 + 1);
+        o += '.';
+        o.append(digits + exp10 + 1, nd - exp10 - 1);
+    }
+}
+bool get_f32(const char* b, const char* e, float* out) {
+    if (b < e && *b == '+') b++;  // Rust's f32::from_str accepts a leading '+', from_chars does not
+    const auto r = std::from_chars(b, e, *out, std::chars_format::general);
+    return r.ec == std::errc() && r.ptr == e && !std::isnan(*out);
+}
+}  // namespace
+
+// `count` targets -> text.  moves / policy are [count][amax] (nmoves[i] entries used).  TZ_ECAPACITY if `cap` is too
+// small (a line needs at most 160 + 32 * nmoves bytes).
+int tz_format_targets(int n, int count, const tz_state* states, const uint16_t* moves, const float* policy,
+                      const int32_t* nmoves, int amax, const float* value, const float* ube, char* out, uint64_t cap,
+                      uint64_t* written_out) {
+    if (!states || !moves || !policy || !nmoves || !value || !ube || !out || !written_out || count < 0 || amax <= 0)
+        return tz_fail(TZ_EINVAL, "tz_format_targets: bad argument");
+    std::string o;
+    o.reserve((size_t)count * 1024);
+    char buf[256];
+    for (int i = 0; i < count; i++) {
+        int rc = tz_state_to_tps(states + i, buf, sizeof buf);
+        if (rc) return rc;
+        o += buf;
+        o += ';';
+        put_f32(o, value[i]);
+        o += ';';
+        put_f32(o, ube[i]);
+        o += ';';
+        if (nmoves[i] < 0 || nmoves[i] > amax) return tz_fail(TZ_EINVAL, "tz_format_targets: nmoves out of range");
+        for (int k = 0; k < nmoves[i]; k++) {
+            if (k) o += ',';
+            rc = tz_move_to_ptn(n, moves[(size_t)i * amax + k], buf, sizeof buf);
+            if (rc) return rc;
+            o += buf;
+            o += ':';
+            put_f32(o, policy[(size_t)i * amax + k]);
+        }
+        o += '\n';
+    }
+    *written_out = o.size();
+    if (o.size() > cap) return tz_fail(TZ_ECAPACITY, "tz_format_targets: output buffer too small");
+    memcpy(out, o.data(), o.size());
+    return TZ_OK;
+}
+
+// Parses complete lines of `text` (up to max_targets of them).  Lines that do not parse are skipped, as the
+// reference's filter_map(|line| line.parse().ok()) does (learn/src/main.rs:308); *consumed_out = bytes up to and
+// including the last line looked at, so a half-written last line is left for the next call.
+int tz_parse_targets(const char* text, uint64_t len, int n, int half_komi, int max_targets, int amax, tz_state* states,
+                     uint16_t* moves, float* policy, int32_t* nmoves, float* value, float* ube, int32_t* count_out,
+                     uint64_t* consumed_out, int32_t* skipped_out) {
+    if (!text || !states || !moves || !policy || !nmoves || !value || !ube || !count_out || !consumed_out || amax <= 0)
+        return tz_fail(TZ_EINVAL, "tz_parse_targets: bad argument");
+    int count = 0, skipped = 0;
+    uint64_t pos = 0;
+    std::string tmp;
+    while (pos < len && count < max_targets) {
+        const char* b = text + pos;
+        const char* nl = (const char*)memchr(b, '\n', len - pos);
+        if (!nl) break;
+        const char* e = nl;
+        pos = (uint64_t)(nl - text) + 1;
+        while (e > b && (e[-1] == '\r' || e[-1] == ' ')) e--;
+        bool ok = false;
+        do {
+            const char* s1 = (const char*)memchr(b, ';', e - b);
+            if (!s1) break;
+            const char* s2 = (const char*)memchr(s1 + 1, ';', e - s1 - 1);
+            if (!s2) break;
+            const char* s3 = (const char*)memchr(s2 + 1, ';', e - s2 - 1);
+            if (!s3) break;
+            tmp.assign(b, s1);
+            if (tz_state_from_tps(tmp.c_str(), n, half_komi, states + count)) break;
+            if (!get_f32(s1 + 1, s2, value + count) || !get_f32(s2 + 1, s3, ube + count)) break;
+            int k = 0;
+            const char* p = s3 + 1;
+            bool bad = p >= e;
+            while (!bad && p < e) {
+                const char* comma = (const char*)memchr(p, ',', e - p);
+                const char* item_end = comma ? comma : e;
+                const char* colon = (const char*)memchr(p, ':', item_end - p);
+                if (!colon || k >= amax) {
+                    bad = true;
+                    break;
+                }
+                tmp.assign(p, colon);
+                if (tz_move_from_ptn(n, tmp.c_str(), moves + (size_t)count * amax + k) ||
+                    !get_f32(colon + 1, item_end, policy + (size_t)count * amax + k)) {
+                    bad = true;
+                    break;
+                }
+                k++;
+                p = comma ? comma + 1 : e;
+                if (comma && p >= e) bad = true;  // trailing comma
+            }
+            if (bad) break;
+            nmoves[count] = k;
+            ok = true;
+        } while (0);
+        if (ok) count++;
+        else skipped++;
+    }
+    *count_out = count;
+    *consumed_out = pos;
+    if (skipped_out) *skipped_out = skipped;
     return TZ_OK;
 }
 

@@ -41,6 +41,77 @@ def parse_target(line, n, half_komi):
         np.float32(value), np.float32(ube)
 
 
+def _amax(n):
+    return 512 if n < 6 else 1024
+
+
+def columns(targets, n):
+    """list of (state, moves, policy, value, ube) -> padded arrays (states, moves, policy, nmoves, value, ube)."""
+    T, amax = len(targets), _amax(n)
+    states = np.zeros(T, api.STATE_DTYPE)
+    moves = np.zeros((T, amax), np.uint16)
+    policy = np.zeros((T, amax), np.float32)
+    nmoves = np.zeros(T, np.int32)
+    value = np.zeros(T, np.float32)
+    ube = np.zeros(T, np.float32)
+    for i, (st, mv, pol, v, u) in enumerate(targets):
+        k = len(mv)
+        states[i] = st
+        moves[i, :k] = mv
+        policy[i, :k] = pol
+        nmoves[i], value[i], ube[i] = k, v, u
+    return states, moves, policy, nmoves, value, ube
+
+
+def format_targets(n, targets):
+    """All lines of a batch of targets in one native call (tz_format_targets): same bytes as format_target."""
+    import ctypes as C
+
+    from . import _lib
+
+    if not targets:
+        return ""
+    states, moves, policy, nmoves, value, ube = columns(targets, n)
+    cap = int(len(targets) * 160 + int(nmoves.sum()) * 32)
+    out = C.create_string_buffer(cap)
+    written = C.c_uint64()
+    _lib.check(_lib.load().tz_format_targets(n, len(targets), states.ctypes.data, moves.ctypes.data, policy.ctypes.data,
+                                             nmoves.ctypes.data, moves.shape[1], value.ctypes.data, ube.ctypes.data, out, cap,
+                                             C.byref(written)))
+    return out.raw[:written.value].decode()
+
+
+def parse_targets(data, n, half_komi, chunk=8192):
+    """Complete lines of `data` (bytes) -> (targets, bytes consumed, lines skipped), natively (tz_parse_targets)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib, amax = _lib.load(), _amax(n)
+    targets, consumed, skipped = [], 0, 0
+    while True:
+        states = np.zeros(chunk, api.STATE_DTYPE)
+        moves = np.zeros((chunk, amax), np.uint16)
+        policy = np.zeros((chunk, amax), np.float32)
+        nmoves = np.zeros(chunk, np.int32)
+        value = np.zeros(chunk, np.float32)
+        ube = np.zeros(chunk, np.float32)
+        cnt, used, skp = C.c_int32(), C.c_uint64(), C.c_int32()
+        view = data[consumed:]
+        _lib.check(lib.tz_parse_targets(view, len(view), n, half_komi, chunk, amax, states.ctypes.data, moves.ctypes.data,
+                                        policy.ctypes.data, nmoves.ctypes.data, value.ctypes.data, ube.ctypes.data,
+                                        C.byref(cnt), C.byref(used), C.byref(skp)))
+        for i in range(cnt.value):
+            k = int(nmoves[i])
+            # a 1-element slice copy keeps the struct's padding bytes zero (np.void.copy() does not)
+            targets.append((states[i:i + 1].copy()[0], moves[i, :k].copy(), policy[i, :k].copy(), np.float32(value[i]), np.float32(ube[i])))
+        consumed += used.value
+        skipped += skp.value
+        if cnt.value < chunk or used.value == 0:
+            break
+    return targets, consumed, skipped
+
+
 def result_string(reason, winner):
     """takparse GameResult as fast-tak converts it (GameResult::try_from(env.result()), target.rs:226-230)."""
     if winner == 2:

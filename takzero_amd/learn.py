@@ -140,19 +140,10 @@ class TargetBuffer:
         with open(path, "rb") as f:
             f.seek(self.seek)
             data = f.read()
-        end = data.rfind(b"\n")
-        if end < 0:
-            return 0
-        self.seek += end + 1
-        added = 0
-        for raw in data[:end].split(b"\n"):
-            try:
-                target = formats.parse_target(raw.decode() + "\n", self.n, self.half_komi)
-            except Exception:
-                continue  # filter_map(|line| line.parse().ok())
-            self.items.append([target, self.forced_uses, model_steps])
-            added += 1
-        return added
+        targets, consumed, _skipped = formats.parse_targets(data, self.n, self.half_komi)  # bad lines are skipped (:308)
+        self.seek += consumed
+        self.items.extend([t, self.forced_uses, model_steps] for t in targets)
+        return len(targets)
 
     def take(self, rng, count):
         """shuffle, drain the last `count` (create_batch, :493-499)."""
@@ -218,7 +209,7 @@ def pre_training(trainer, mcts, rng_seed, directory=None, initial_targets=INITIA
     buffer = [buffer[i] for i in order]
     if directory is not None:
         with open(os.path.join(directory, "targets-initial.txt"), "w") as f:
-            f.write("".join(formats.format_target(mcts.n, *t) for t in buffer))
+            f.write(formats.format_targets(mcts.n, buffer))
     B, losses = trainer.batch, []
     from . import augment as AU
 

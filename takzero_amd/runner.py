@@ -151,8 +151,45 @@ def wait_until_needed(directory, which, cap, watcher, sleep=1.0, max_wait=None, 
             time.sleep(sleep)
 
 
+class AsyncAppender:
+    """One writer thread that formats and appends what the search loop hands over, in order.  Formatting thousands of
+    target lines per move is native code (tz_format_targets) and the search itself sits inside ctypes calls, both
+    with the interpreter lock released, so the file work overlaps the next move's search instead of delaying it."""
+
+    def __init__(self):
+        import queue
+        import threading
+
+        self.q = queue.Queue(maxsize=8)   # bounded: back-pressure instead of unbounded memory if the disk stalls
+        self.error = None
+        self.thread = threading.Thread(target=self._run, name="tz-appender", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            try:
+                if self.error is None:
+                    job()
+            except Exception as e:   # surfaced by the next submit() / close() on the search thread
+                self.error = e
+
+    def submit(self, job):
+        if self.error is not None:
+            raise self.error
+        self.q.put(job)
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+
 def append_lines(path, lines):
-    if not lines:
+    if not lines or not any(lines):
         return
     with open(path, "a") as f:  # OpenOptions::append(true).create(true)
         f.write("".join(lines))
@@ -177,22 +214,29 @@ def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, wor
         watcher = BroadcastModelWatcher(mcts.agent, directory, rank) if broadcast_model and world > 1 else \
             ModelWatcher(mcts.agent, directory)
     suffix = "" if world == 1 or gather else "-rank%d" % rank
-    step = 0
-    while moves is None or step < moves:
-        wait_until_needed(directory, 0, MAX_SELFPLAY_BUFFER_LEN, watcher, sleep, max_wait, log)
-        targets, replays = sp.play_move()
-        if gather and world > 1:
-            targets = all_gather_targets(targets, n)
+    rsuffix = "" if world == 1 else "-rank%d" % rank
+    writer = AsyncAppender()
+
+    def write(targets, replays, expl):
         if not gather or rank == 0:
-            append_lines(os.path.join(directory, "targets-selfplay%s.txt" % suffix),
-                         [formats.format_target(n, *t) for t in targets])
-        rsuffix = "" if world == 1 else "-rank%d" % rank
+            append_lines(os.path.join(directory, "targets-selfplay%s.txt" % suffix), [formats.format_targets(n, targets)])
         append_lines(os.path.join(directory, "replays%s.txt" % rsuffix), [formats.format_replay(n, *r) for r in replays])
         if exploration:
             append_lines(os.path.join(directory, "replays-exploration%s.txt" % rsuffix),
-                         [formats.format_replay(n, *r) for r in sp.exploration_replays])
-            sp.exploration_replays.clear()
-        step += 1
+                         [formats.format_replay(n, *r) for r in expl])
+
+    step = 0
+    try:
+        while moves is None or step < moves:
+            wait_until_needed(directory, 0, MAX_SELFPLAY_BUFFER_LEN, watcher, sleep, max_wait, log)
+            targets, replays = sp.play_move()
+            if gather and world > 1:
+                targets = all_gather_targets(targets, n)   # collectives stay on the search thread
+            expl, sp.exploration_replays = sp.exploration_replays, []
+            writer.submit(lambda t=targets, r=replays, e=expl: write(t, r, e))
+            step += 1
+    finally:
+        writer.close()
     return sp
 
 
@@ -206,20 +250,24 @@ def run_reanalyze(directory, mcts, sims, iterations=None, seed=0, rank=0, world=
     suffix = "" if world == 1 else "-rank%d" % rank
     it = 0
     t0 = time.monotonic()
-    while iterations is None or it < iterations:
-        wait_until_needed(directory, 1, MAX_REANALYZE_BUFFER_LEN, watcher, sleep, max_wait, log)
-        try:
-            ra.buffer.read_new(os.path.join(directory, "replays.txt"))
-        except OSError as err:
-            if log:
-                log("Cannot fill position buffer: %s" % err)
-        if len(ra.buffer.positions) < max(min_positions, mcts.batch):
-            if max_wait is not None and time.monotonic() - t0 > max_wait:
-                raise TimeoutError("not enough positions (%d)" % len(ra.buffer.positions))
-            time.sleep(sleep)  # the reference sleeps 60 s here (reanalyze/src/main.rs:135-142)
-            continue
-        targets = ra.iterate()
-        append_lines(os.path.join(directory, "targets-reanalyze%s.txt" % suffix),
-                     [formats.format_target(n, *t) for t in targets])
-        it += 1
+    writer = AsyncAppender()
+    path = os.path.join(directory, "targets-reanalyze%s.txt" % suffix)
+    try:
+        while iterations is None or it < iterations:
+            wait_until_needed(directory, 1, MAX_REANALYZE_BUFFER_LEN, watcher, sleep, max_wait, log)
+            try:
+                ra.buffer.read_new(os.path.join(directory, "replays.txt"))
+            except OSError as err:
+                if log:
+                    log("Cannot fill position buffer: %s" % err)
+            if len(ra.buffer.positions) < max(min_positions, mcts.batch):
+                if max_wait is not None and time.monotonic() - t0 > max_wait:
+                    raise TimeoutError("not enough positions (%d)" % len(ra.buffer.positions))
+                time.sleep(sleep)  # the reference sleeps 60 s here (reanalyze/src/main.rs:135-142)
+                continue
+            targets = ra.iterate()
+            writer.submit(lambda t=targets: append_lines(path, [formats.format_targets(n, t)]))
+            it += 1
+    finally:
+        writer.close()
     return ra

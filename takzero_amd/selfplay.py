@@ -6,6 +6,8 @@ Gumbel sequential halving (selfplay/src/main.rs:138-153).
 One SelfPlay object drives one GPU's shard of games.  Randomness (openings, Dirichlet / Gumbel
 noise, early-ply move sampling) is drawn here from a counter-keyed numpy generator so that a CPU
 run of the oracle can be fed the same values."""
+import time
+
 import numpy as np
 
 from . import api, formats
@@ -49,6 +51,7 @@ class SelfPlay:
         self.moves_played = 0
         self.positions = 0
         self.exploration_replays = []   # filled by _complete for games searched with beta > 0 (feature "exploration")
+        self.host_s = {"search": 0.0, "record": 0.0, "step": 0.0, "complete": 0.0}  # wall seconds per phase
         mcts.new_openings(self.rng.integers(0, 16, mcts.batch))
         if self.collect:
             self.start_states = mcts.get_positions()
@@ -57,6 +60,7 @@ class SelfPlay:
         """One outer-loop iteration of selfplay::main.  Returns (finished_targets, finished_replays): targets are
         (state, moves, policy, value, ube), replays are (start_state, moves, PTN result)."""
         m, B = self.mcts, self.mcts.batch
+        t0 = time.perf_counter()
         if self.search == "puct":
             m.simulate(self.betas, 1)                       # selfplay/src/main.rs:128
             info = m.root_info()
@@ -80,12 +84,18 @@ class SelfPlay:
                 sampled = m.select_actions_in_selfplay(self.rng, WEIGHTED_RANDOM_PLIES)
                 actions = np.where(early, sampled, actions).astype(np.uint16)
         targets, replays = [], []
+        t1 = time.perf_counter()
         if self.collect:
             self._record(actions)
+        t2 = time.perf_counter()
         m.step(actions)                                     # take_a_step, :238-258
         term = m.restart_terminal_envs(self.rng.integers(0, 16, B))  # :263-329
+        t3 = time.perf_counter()
         if self.collect:
             targets, replays = self._complete(term)
+        t4 = time.perf_counter()
+        for k, v in (("search", t1 - t0), ("record", t2 - t1), ("step", t3 - t2), ("complete", t4 - t3)):
+            self.host_s[k] += v
         self.moves_played += 1
         self.positions += B
         return targets, replays

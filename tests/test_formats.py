@@ -47,3 +47,45 @@ def test_buffer_lengths():
     import pytest
     with pytest.raises(ValueError):
         F.parse_buffer_lengths("12,30,43")
+
+
+def _fields(state):
+    """bytes of a tz_state record with its padding zeroed (numpy leaves the padding of a void scalar undefined)"""
+    from takzero_amd._lib import STATE_DTYPE
+
+    arr = np.zeros(1, STATE_DTYPE)
+    arr[0] = state
+    return arr.tobytes()
+
+
+def test_bulk_target_lines_equal_the_line_by_line_ones():
+    """tz_format_targets / tz_parse_targets (native, thousands of lines per move) against format_target / parse_target."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_learn_host import _targets
+    from takzero_amd import formats as F
+
+    for n in (4, 5, 6):
+        targets = _targets(n, 40, 10 + n)
+        # awkward floats: tiny, huge, negative zero, exact integers, denormal, many digits
+        odd = [1e-10, 3.4e38, -0.0, 1.0, 0.0, 1e-45, 0.1, 123456.79, 16777216.0, 2.5e-7, 0.30000001]
+        st, mv, pol, v, u = targets[0]
+        pol = pol.copy()
+        pol[:min(len(pol), len(odd))] = np.float32(odd[:len(pol)])
+        targets[0] = (st, mv, pol, np.float32(-0.0), np.float32(1e-10))
+        want = "".join(F.format_target(n, *t) for t in targets)
+        got = F.format_targets(n, targets)
+        assert got == want
+        back, consumed, skipped = F.parse_targets(got.encode(), n, 4)
+        assert consumed == len(got.encode()) and skipped == 0 and len(back) == len(targets)
+        for a, b in zip(back, targets):
+            ref = F.parse_target(F.format_target(n, *b), n, 4)
+            assert _fields(a[0]) == _fields(ref[0]) and np.array_equal(a[1], ref[1])
+            assert np.array_equal(a[2].view(np.uint32), ref[2].view(np.uint32))
+            assert np.float32(a[3]).tobytes() == np.float32(ref[3]).tobytes() and np.float32(a[4]) == np.float32(ref[4])
+    # skipping and the half-written tail (learn tails the file while selfplay appends)
+    lines = F.format_targets(5, _targets(5, 3, 1)).splitlines(keepends=True)
+    data = (lines[0] + "not a target\n" + "x5/x5/x5/x5/x5 1 1;0.5;1;a1:0.5,\n" + ";;;\n" + lines[1] + lines[2][:25]).encode()
+    back, consumed, skipped = F.parse_targets(data, 5, 4)
+    assert len(back) == 2 and skipped == 3 and consumed == len(data) - 25
+    assert F.parse_targets(b"", 5, 4) == ([], 0, 0) and F.format_targets(5, []) == ""

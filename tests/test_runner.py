@@ -164,3 +164,18 @@ def test_exploration_feature_writes_truncated_replays_and_filters_targets(tmp_pa
     # exploitation games contribute every position, exploratory ones only those after ply 10: fewer targets than moves
     n_targets = sum(1 for _ in open(os.path.join(d, "targets-selfplay.txt")))
     assert n_targets < sum(len(mv) for _, mv in replays)
+
+
+def test_async_appender_keeps_order_and_surfaces_errors(tmp_path):
+    from takzero_amd import runner as R
+
+    p = str(tmp_path / "out.txt")
+    w = R.AsyncAppender()
+    for i in range(50):
+        w.submit(lambda i=i: R.append_lines(p, ["%d\n" % i]))
+    w.close()
+    assert open(p).read() == "".join("%d\n" % i for i in range(50))
+    w = R.AsyncAppender()
+    w.submit(lambda: R.append_lines(str(tmp_path / "no-such-dir" / "x.txt"), ["a\n"]))
+    with pytest.raises(OSError):
+        w.close()

@@ -25,5 +25,6 @@ for mv in range(moves):
     peak = max(peak, used)
     if mv % 10 == 9:
         info = mcts.root_info()
-        print("move %d: pool %d/%d (peak %d), finished games %d, targets %d, max ply %d, %.1fs" % (
-            mv + 1, used, cap, peak, finished, ntargets, int(info["ply"].max()), time.time() - t0), flush=True)
+        print("move %d: pool %d/%d (peak %d), finished games %d, targets %d, max ply %d, %.1fs  host phases %s" % (
+            mv + 1, used, cap, peak, finished, ntargets, int(info["ply"].max()), time.time() - t0,
+            {k: round(v, 2) for k, v in sp.host_s.items()}), flush=True)
