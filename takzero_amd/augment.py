@@ -65,3 +65,27 @@ def augment_target(target, rng, n):
     st, moves, pol, value, ube = target
     sym = int(rng.integers(0, 8))
     return augment_state(st, sym, n), augment_moves(moves, sym, n), pol, value, ube
+
+
+def augment_batch(states, moves, rows, rng, n):
+    """Augment::augment for a whole batch at once: states [B] records, moves = all policies' move indices
+    concatenated, rows[i] = the target move i belongs to.  One symmetry per target, drawn uniformly."""
+    perm, dirs = tables(n)
+    B, nn, patterns = len(states), n * n, (1 << n) - 2
+    sym = rng.integers(0, 8, B)
+    out = states.copy()
+    target_sq = perm[sym]                       # [B][nn]: where each square goes
+    b_index = np.arange(B)[:, None]
+    for field in ("colors", "height", "top"):
+        old = states[field]
+        new = np.zeros_like(old)
+        new[b_index, target_sq] = old[:, :nn]
+        out[field] = new
+    idx = np.asarray(moves, np.int64)
+    msym = sym[rows]
+    ch, sq = idx // nn, idx % nn
+    spread = ch >= 3
+    d = np.where(spread, (ch - 3) // patterns, 0)
+    pat = np.where(spread, (ch - 3) % patterns, 0)
+    ch2 = np.where(spread, 3 + pat + patterns * dirs[msym, d], ch)
+    return out, ch2 * nn + perm[msym, sq]

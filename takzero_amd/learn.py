@@ -12,22 +12,29 @@ LEARNING_RATE = 1e-4    # learn/src/main.rs:46
 PARAM, GRAD, ADAM_M, ADAM_V = 0, 1, 2, 3
 
 
-def target_tensors(targets, n):
-    """create_input_and_target_tensors (learn/src/main.rs:330-374) without the random symmetry: states, dense policy
-    target (policy_tensor), mask of non-legal outputs (move_mask), value and UBE targets (raw variances; the log and
-    clamp are applied inside the step).  `targets` = (state, moves, policy, value, ube) tuples."""
+def target_tensors(targets, n, rng=None):
+    """create_input_and_target_tensors (learn/src/main.rs:330-374): states, dense policy target (policy_tensor), mask of
+    non-legal outputs (move_mask), value and UBE targets (raw variances; the log and clamp are applied inside the
+    step).  `targets` = (state, moves, policy, value, ube) tuples; with `rng` every target is first put through a
+    random board symmetry (target.augment(rng), target.rs:41-53).  Vectorised over the batch."""
     B, out = len(targets), api.policy_size(n)
     states = np.zeros(B, api.STATE_DTYPE)
+    for i, t in enumerate(targets):
+        states[i] = t[0]
+    counts = np.fromiter((len(t[1]) for t in targets), np.int64, B)
+    moves = np.concatenate([np.asarray(t[1], np.int64) for t in targets]) if B else np.zeros(0, np.int64)
+    probs = np.concatenate([np.asarray(t[2], np.float32) for t in targets]) if B else np.zeros(0, np.float32)
+    rows = np.repeat(np.arange(B), counts)
+    if rng is not None:
+        from . import augment as AU
+
+        states, moves = AU.augment_batch(states, moves, rows, rng, n)
     policy = np.zeros((B, out), np.float32)
     mask = np.ones((B, out), np.uint8)
-    value = np.zeros(B, np.float32)
-    ube = np.zeros(B, np.float32)
-    for i, (st, moves, pol, v, u) in enumerate(targets):
-        states[i] = st
-        idx = np.asarray(moves, np.int64)
-        policy[i, idx] = pol
-        mask[i, idx] = 0
-        value[i], ube[i] = v, u
+    policy[rows, moves] = probs
+    mask[rows, moves] = 0
+    value = np.fromiter((t[3] for t in targets), np.float32, B)
+    ube = np.fromiter((t[4] for t in targets), np.float32, B)
     return states, policy, mask, value, ube
 
 
@@ -146,11 +153,16 @@ class TargetBuffer:
         return len(targets)
 
     def take(self, rng, count):
-        """shuffle, drain the last `count` (create_batch, :493-499)."""
-        rng.shuffle(self.items)
-        batch = self.items[len(self.items) - count:]
-        del self.items[len(self.items) - count:]
-        return batch
+        """`count` targets drawn uniformly without replacement and removed — what shuffling the whole buffer and
+        draining its tail does (create_batch, :493-499), in O(count) instead of O(len)."""
+        pick = sorted((int(i) for i in rng.choice(len(self.items), size=count, replace=False)), reverse=True)
+        batch = []
+        for i in pick:              # swap-remove, largest index first so earlier picks stay valid
+            batch.append(self.items[i])
+            self.items[i] = self.items[-1]
+            self.items.pop()
+        order = rng.permutation(count)
+        return [batch[i] for i in order]
 
     def give_back(self, batch):
         for item in batch:  # TargetWithContext::reuse
@@ -176,18 +188,16 @@ def model_path_with_most_steps(directory):
 
 def create_batch(using_reanalyze, exploitation, reanalyze, rng, n, batch=BATCH_SIZE, augment=True):
     """create_batch + create_input_and_target_tensors (:486-516, :330-374)."""
-    from . import augment as AU
-
     if using_reanalyze:
         a, b = exploitation.take(rng, batch // 2), reanalyze.take(rng, batch // 2)
         items = a + b
     else:
         a, b = exploitation.take(rng, batch), []
         items = a
-    targets = [AU.augment_target(it[0], rng, n) if augment else it[0] for it in items]
+    tensors = target_tensors([it[0] for it in items], n, rng if augment else None)
     exploitation.give_back(a)
     reanalyze.give_back(b)
-    return target_tensors(targets, n)
+    return tensors
 
 
 def pre_training(trainer, mcts, rng_seed, directory=None, initial_targets=INITIAL_RANDOM_TARGETS,
@@ -211,25 +221,28 @@ def pre_training(trainer, mcts, rng_seed, directory=None, initial_targets=INITIA
         with open(os.path.join(directory, "targets-initial.txt"), "w") as f:
             f.write(formats.format_targets(mcts.n, buffer))
     B, losses = trainer.batch, []
-    from . import augment as AU
-
     for s in range(min(steps, len(buffer) // B)):
-        chunk = [AU.augment_target(t, rng, mcts.n) for t in buffer[s * B:(s + 1) * B]]
-        losses.append(trainer.step(*target_tensors(chunk, mcts.n), train_ube=False))
+        losses.append(trainer.step(*target_tensors(buffer[s * B:(s + 1) * B], mcts.n, rng), train_ube=False))
         if log and s % 100 == 0:
             log("pre-training step %d: %r" % (s, losses[-1]))
     return losses
 
 
-def save_model(trainer, path, hash_net=None):
-    """Network::save (network/mod.rs:16-18; net6_simhash.rs:152-171 also writes bitvec.bin beside the model)."""
+def save_model(trainer, path, hash_net=None, background=None):
+    """Network::save (network/mod.rs:16-18; net6_simhash.rs:152-171 also writes bitvec.bin beside the model).  The
+    weights are read back from the GPU here; with `background` (a runner.AsyncAppender) the archive itself is written
+    by that thread while training goes on."""
     import os
 
     from . import ot
 
-    ot.save_ot(path, trainer.tensors())
+    snapshot = trainer.tensors()
     if hash_net is not None:
         hash_net.save_bitset(os.path.join(os.path.dirname(str(path)), "bitvec.bin"))
+    if background is None:
+        ot.save_ot(path, snapshot)
+    else:
+        background.submit(lambda: ot.save_ot(path, snapshot))
 
 
 def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mcts=None, hash_net=None,
@@ -245,7 +258,10 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
 
     from . import formats, ot
 
+    from .runner import AsyncAppender
+
     n, rng = trainer.n, np.random.default_rng([seed, 5])
+    saver = AsyncAppender()   # model files are written behind the training loop, in order
     resume = model_path_with_most_steps(directory)
     if resume is not None:
         starting_steps = resume[0]
@@ -255,8 +271,6 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
         save_model(trainer, os.path.join(directory, "model_0000000.ot"), hash_net)
     if restart_targets is not None:
         # --restart-targets (:126-147): one pass over a saved target file, UBE head not trained
-        from . import augment as AU
-
         with open(restart_targets) as f:
             saved = []
             for line in f:
@@ -267,8 +281,7 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
         rng.shuffle(saved)
         B = trainer.batch
         for s in range(len(saved) // B):
-            chunk = [AU.augment_target(t, rng, n) for t in saved[s * B:(s + 1) * B]]
-            trainer.step(*target_tensors(chunk, n), train_ube=False)
+            trainer.step(*target_tensors(saved[s * B:(s + 1) * B], n, rng), train_ube=False)
             starting_steps += 1
         save_model(trainer, os.path.join(directory, "model_%07d.ot" % starting_steps), hash_net)
     elif resume is None:
@@ -283,36 +296,56 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
     model_steps = starting_steps
     done = 0
     t0 = time.monotonic()
-    while steps is None or done < steps:
-        model_steps += 1
-        using_reanalyze = restart_targets is not None or model_steps >= steps_before_reanalyze
-        while True:
-            if time.monotonic() - last_loaded >= read_interval:
-                for buf, name, use in ((exploitation, "targets-selfplay.txt", True),
-                                       (reanalyze, "targets-reanalyze.txt", using_reanalyze)):
-                    if use:
-                        try:
-                            buf.fill(os.path.join(directory, name), model_steps)
-                        except OSError as err:
-                            if log:
-                                log("Cannot read %s: %s" % (name, err))
-                last_loaded = time.monotonic()
-                with open(os.path.join(directory, "buffer_lengths.txt"), "w") as f:
-                    f.write(formats.format_buffer_lengths(len(exploitation), len(reanalyze)))
-            if len(exploitation) >= min_selfplay and (not using_reanalyze or len(reanalyze) >= min_reanalyze):
-                break
-            if max_wait is not None and time.monotonic() - t0 > max_wait:
-                raise TimeoutError("not enough targets (%d selfplay, %d reanalyze)" % (len(exploitation), len(reanalyze)))
-            time.sleep(sleep)
-        tensors = create_batch(using_reanalyze, exploitation, reanalyze, rng, n, trainer.batch)
-        losses = trainer.step(*tensors, train_ube=True)
+    # The step of batch k runs on a worker thread (inside a ctypes call, interpreter lock released) while this thread
+    # samples, augments and densifies batch k+1; results are collected in step order, so logs and model files are those
+    # of the sequential loop.
+    from concurrent.futures import ThreadPoolExecutor
+
+    def finish(step_no, fut, states):
+        losses = fut.result()
         if hash_net is not None:
-            hash_net.hash_indices(tensors[0], update=True)  # net.update_counts(&tensors.input), :418
+            hash_net.hash_indices(states, update=True)  # net.update_counts(&tensors.input), :418
         if log:
-            log("step %d: loss_policy %.5f loss_value %.5f loss_ube %.5f" % ((model_steps,) + losses))
-        if model_steps % steps_per_save == 0:
-            save_model(trainer, os.path.join(directory, "model_latest.ot"), hash_net)
-        if model_steps % steps_per_checkpoint == 0:
-            save_model(trainer, os.path.join(directory, "model_%07d.ot" % model_steps), hash_net)
-        done += 1
+            log("step %d: loss_policy %.5f loss_value %.5f loss_ube %.5f" % ((step_no,) + losses))
+        if step_no % steps_per_save == 0:
+            save_model(trainer, os.path.join(directory, "model_latest.ot"), hash_net, saver)
+        if step_no % steps_per_checkpoint == 0:
+            save_model(trainer, os.path.join(directory, "model_%07d.ot" % step_no), hash_net, saver)
+
+    pending = None
+    with ThreadPoolExecutor(1) as pool:
+        try:
+            while steps is None or done < steps:
+                model_steps += 1
+                using_reanalyze = restart_targets is not None or model_steps >= steps_before_reanalyze
+                while True:
+                    if time.monotonic() - last_loaded >= read_interval:
+                        for buf, name, use in ((exploitation, "targets-selfplay.txt", True),
+                                               (reanalyze, "targets-reanalyze.txt", using_reanalyze)):
+                            if use:
+                                try:
+                                    buf.fill(os.path.join(directory, name), model_steps)
+                                except OSError as err:
+                                    if log:
+                                        log("Cannot read %s: %s" % (name, err))
+                        last_loaded = time.monotonic()
+                        with open(os.path.join(directory, "buffer_lengths.txt"), "w") as f:
+                            f.write(formats.format_buffer_lengths(len(exploitation), len(reanalyze)))
+                    if len(exploitation) >= min_selfplay and (not using_reanalyze or len(reanalyze) >= min_reanalyze):
+                        break
+                    if max_wait is not None and time.monotonic() - t0 > max_wait:
+                        raise TimeoutError("not enough targets (%d selfplay, %d reanalyze)" % (len(exploitation), len(reanalyze)))
+                    time.sleep(sleep)
+                tensors = create_batch(using_reanalyze, exploitation, reanalyze, rng, n, trainer.batch)
+                if pending is not None:
+                    finish(*pending)
+                pending = (model_steps, pool.submit(trainer.step, *tensors, train_ube=True), tensors[0])
+                time.sleep(0.0005)   # hand the interpreter lock over so the worker enters its (lock-free) native call now
+                done += 1
+        finally:
+            try:
+                if pending is not None:
+                    finish(*pending)
+            finally:
+                saver.close()
     return model_steps

@@ -115,6 +115,12 @@ def save_ot(path, tensors):
                 a.tofile(raw)
                 mf.write("%s %d %s %s\n" % (name, a.ndim, " ".join(str(d) for d in a.shape), raw))
         part = path + ".part"
-        subprocess.check_call([exe, manifest, part])
+        # the archive writer is a background helper: one thread, low priority, so that it never competes with the
+        # threads that feed the GPU
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        cmd = [exe, manifest, part]
+        if os.path.exists("/usr/bin/nice"):
+            cmd = ["/usr/bin/nice", "-n", "10"] + cmd
+        subprocess.check_call(cmd, env=env)
         os.replace(part, path)
     return path

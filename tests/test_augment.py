@@ -49,3 +49,30 @@ def test_augment_target_keeps_probabilities_with_their_moves():
         seen.add(tuple(int(m) for m in mv))
         assert np.array_equal(p, pol) and (v, u) == (0.5, 1.0) and len(set(mv.tolist())) == len(moves)
     assert len(seen) >= 4  # several different symmetries were drawn
+
+
+def test_batch_augmentation_equals_the_per_target_one():
+    from takzero_amd import augment as AU
+
+    oracle = O.load()
+    n, B = 5, 24
+    states = O.states_array(random_positions(oracle, O, n, 4, B, 5, min_ply=4, max_ply=30))
+    per = [np.array(O.possible_moves(oracle, O.TzState.from_buffer_copy(states[i].tobytes())), np.int64) for i in range(B)]
+    rows = np.repeat(np.arange(B), [len(m) for m in per])
+
+    class Fixed:  # hands out a chosen symmetry per target
+        def __init__(self, sym):
+            self.sym = sym
+
+        def integers(self, lo, hi, size):
+            return self.sym
+
+    sym = np.arange(B) % 8
+    out_states, out_moves = AU.augment_batch(states, np.concatenate(per), rows, Fixed(sym), n)
+    off = 0
+    for i in range(B):
+        want_state = AU.augment_state(states[i], int(sym[i]), n)
+        for f in ("colors", "height", "top", "stones", "caps", "to_move", "ply"):
+            assert np.array_equal(out_states[i][f], want_state[f]), (i, f)
+        assert np.array_equal(out_moves[off:off + len(per[i])], AU.augment_moves(per[i], int(sym[i]), n).astype(np.int64))
+        off += len(per[i])

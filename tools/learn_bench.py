@@ -40,6 +40,31 @@ def main():
     flop = 3 * 1.1975e9 * B  # forward + data gradient + weight gradient of every conv / linear (RND is not trained)
     line = {"metric": "learn steps/s", "value": 1.0 / dt, "ms_per_step": dt * 1e3, "batch": B, "positions_per_s": B / dt,
             "tflops": flop / dt / 1e12, "losses": losses, "dtype": "f32"}
+    if "--loop" in sys.argv:
+        # learn::main end to end: target file tailing, sampling with forced uses, augmentation, dense tensors, step,
+        # model files every 100 steps — on a directory holding 20 000 random-game targets
+        import tempfile
+
+        from takzero_amd import formats as F
+
+        d = tempfile.mkdtemp()
+        while len(targets) < 20000:
+            targets.extend(sp.play_move()[0])
+        with open(os.path.join(d, "targets-selfplay.txt"), "w") as f:
+            f.write(F.format_targets(n, targets))
+        loop_steps = 350
+        stamps = []
+        L.run_learn(d, tr, steps=loop_steps, seed=1, pre_train_mcts=None, min_selfplay=10000,
+                    steps_before_reanalyze=10 ** 9, read_interval=10.0, sleep=0.01, max_wait=60,
+                    log=lambda msg: stamps.append(time.perf_counter()))
+        dt_loop = (stamps[-1] - stamps[49]) / (len(stamps) - 50)   # steady state: after start-up saves and the first read
+        import numpy as _np
+
+        gaps = _np.diff(_np.array(stamps[49:])) * 1e3
+        line["loop_ms_per_step_median"] = float(_np.median(gaps))
+        line["loop_ms_slowest_steps"] = [(int(i) + 50, round(float(gaps[i]), 1)) for i in _np.argsort(gaps)[-8:]]
+        line["loop_ms_per_step"] = dt_loop * 1e3
+        line["loop_steps_per_s"] = 1.0 / dt_loop
     print(json.dumps(line))
 
 
