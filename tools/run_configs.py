@@ -98,8 +98,36 @@ def gumbel(moves=3, games=4096, budget=768, k=64):
     return out
 
 
+def directory_loop(moves=100, games=4096, sims=400):
+    """selfplay::main end to end (runner.run_selfplay: back-pressure file, target / replay files written by the
+    appender thread) against the bare search loop of bench.py, over enough moves that games finish and targets flow."""
+    from takzero_amd import runner as R
+
+    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
+    mcts = A.BatchedMCTS(games, 5, 4, agent=net)
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "buffer_lengths.txt"), "w") as f:
+        f.write(F.format_buffer_lengths(0, 0))
+    t0 = time.perf_counter()
+    sp = R.run_selfplay(d, mcts, sims, moves=moves, seed=0, search="puct", watch_model=False, max_wait=60)
+    dt = time.perf_counter() - t0
+    sims_total, _ = mcts.counters()
+    tpath = os.path.join(d, "targets-selfplay.txt")
+    out = {"config": "run_selfplay on a directory: 5x5, %d games, %d sims/move, %d moves" % (games, sims, moves),
+           "s_per_move": dt / moves, "sims_per_s": sims_total / dt, "search_s": sp.host_s["search"],
+           "record_s": sp.host_s["record"], "complete_s": sp.host_s["complete"], "wall_s": dt,
+           "targets_written": sum(1 for _ in open(tpath)) if os.path.exists(tpath) else 0,
+           "targets_file_mb": os.path.getsize(tpath) / 1e6 if os.path.exists(tpath) else 0}
+    mcts.close()
+    net.close()
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["4", "5"]
+    if "dir" in which:
+        print(json.dumps(directory_loop()), flush=True)
     if "gumbel" in which:
         print(json.dumps(gumbel()), flush=True)
     if "4" in which:
