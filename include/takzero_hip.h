@@ -191,6 +191,9 @@ int tz_search_root_children(tz_search* s, int amax, uint16_t* move_idx, uint32_t
 int tz_search_select_best_actions(tz_search* s, uint16_t* actions_out /*[batch]*/);
 /* Node::improved_policy(visitations) per root (policy.rs:23-48), [batch][amax]. */
 int tz_search_improved_policy(tz_search* s, float visitations, int amax, float* policy_out);
+/* the same with one visitation count per game: reanalyze passes each root's most_visited_count()
+ * (reanalyze/src/main.rs:196-202) */
+int tz_search_improved_policy_each(tz_search* s, const float* visitations, int amax, float* policy_out);
 /* Node::ube_target(beta) per root (node/mod.rs:215-230). */
 int tz_search_ube_target(tz_search* s, float beta, float* out /*[batch]*/);
 /* BatchedMCTS::step (batched.rs:131-144): descend (subtree reuse) + env.step; skipped for

@@ -32,7 +32,7 @@ SYMBOLS = [
     "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_search_terminal_details", "tz_search_play_moves",
     "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
     "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
-    "tz_format_targets", "tz_parse_targets",
+    "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each",
 ]
 
 _lib = None
@@ -85,6 +85,7 @@ def load():
     lib.tz_search_root_children.argtypes = [vp, ci] + [vp] * 7
     lib.tz_search_select_best_actions.argtypes = [vp, vp]
     lib.tz_search_improved_policy.argtypes = [vp, cf, ci, vp]
+    lib.tz_search_improved_policy_each.argtypes = [vp, vp, ci, vp]
     lib.tz_search_ube_target.argtypes = [vp, cf, vp]
     lib.tz_search_step.argtypes = [vp, vp]
     lib.tz_search_restart_terminal.argtypes = [vp, vp, vp]

@@ -296,6 +296,15 @@ class BatchedMCTS:
         check(self.lib.tz_search_improved_policy(self.h, visitations, amax, out.ctypes.data))
         return out
 
+    def improved_policy_each(self, visitations, amax=None):
+        """improved_policy with one visitation count per game (reanalyze/src/main.rs:196-202)."""
+        if amax is None:
+            amax = max(1, int(self.root_info()["n_children"].max()))
+        v = np.ascontiguousarray(visitations, np.float32)
+        out = np.zeros((self.batch, amax), np.float32)
+        check(self.lib.tz_search_improved_policy_each(self.h, v.ctypes.data, amax, out.ctypes.data))
+        return out
+
     def ube_target(self, beta):
         out = np.zeros(self.batch, np.float32)
         check(self.lib.tz_search_ube_target(self.h, beta, out.ctypes.data))

@@ -451,14 +451,15 @@ float h_to_notnan(HEv e) {
 }
 }  // namespace
 
-int tz_search_improved_policy(tz_search* s, float visitations, int amax, float* policy_out) {
+// Node::improved_policy (policy.rs:20-62) for every root; visitations[g] (or the one value when `each` is null)
+static int improved_policy_impl(tz_search* s, float visitations, const float* each, int amax, float* policy_out) {
     if (!s || !policy_out || amax <= 0) return tz_fail(TZ_EINVAL, "tz_search_improved_policy: bad argument");
     RootData r;
     int rc = fetch_roots(s, r);
     if (rc) return rc;
-    const float sq = sqrtf(visitations);
     std::vector<float> p;
     for (int g = 0; g < s->d.batch; g++) {
+        const float sq = sqrtf(each ? each[g] : visitations);
         const int nc = (int)r.info[g].n_children;
         if (nc > amax) return tz_fail(TZ_EINVAL, "tz_search_improved_policy: amax too small");
         const HEv root{r.info[g].eval_tag, r.info[g].eval.ply};
@@ -482,6 +483,15 @@ int tz_search_improved_policy(tz_search* s, float visitations, int amax, float* 
         for (int i = 0; i < amax; i++) policy_out[(size_t)g * amax + i] = i < nc ? p[i] / sum : 0.0f;
     }
     return TZ_OK;
+}
+
+int tz_search_improved_policy(tz_search* s, float visitations, int amax, float* policy_out) {
+    return improved_policy_impl(s, visitations, nullptr, amax, policy_out);
+}
+
+int tz_search_improved_policy_each(tz_search* s, const float* visitations, int amax, float* policy_out) {
+    if (!visitations) return tz_fail(TZ_EINVAL, "tz_search_improved_policy_each: null visitations");
+    return improved_policy_impl(s, 0.0f, visitations, amax, policy_out);
 }
 
 int tz_search_ube_target(tz_search* s, float beta, float* out) {

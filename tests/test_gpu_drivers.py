@@ -136,6 +136,13 @@ def test_reanalyze_iteration(oracle, tmp_path):
             back = st.copy()
             back["reversible_plies"] = 0  # not representable in TPS (target.rs:322-326)
             assert F.parse_target(line, n, 4)[0].tobytes() == back.tobytes()
+    # the per-game entry point equals the scalar one called once per distinct visitation count
+    ch = mcts.root_children()
+    mvc = ch["visits"].max(axis=1).astype(np.float32)
+    each = mcts.improved_policy_each(mvc, ch["visits"].shape[1])
+    for v in np.unique(mvc):
+        rows = mvc == v
+        assert np.array_equal(each[rows], mcts.improved_policy(float(v), ch["visits"].shape[1])[rows])
     # sharding: rank r of 2 sees every second replay line
     b0, b1 = RA.PositionBuffer(mcts, n, 4, 0, 2), RA.PositionBuffer(mcts, n, 4, 1, 2)
     full = RA.PositionBuffer(mcts, n, 4)
