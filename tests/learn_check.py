@@ -29,11 +29,27 @@ for name, g, t_ in zip(("policy", "value", "ube"), tr.outputs(), wouts):
     t_ = t_.detach().numpy()
     print("out %-8s max|x| %.3f  max diff %.3e" % (name, np.abs(t_).max(), np.abs(g - t_).max()))
 print("losses", got, [float(x.detach()) for x in want])
+# the same graph in float64: which of the two fp32 computations is closer to the exact gradient?
+p64 = {k: (v.detach().double().requires_grad_(v.requires_grad)) for k, v in LT.make_params(w).items()}
+w64, _ = LT.losses(p64, torch.from_numpy(planes).double(), torch.from_numpy(mask.astype(bool)), torch.from_numpy(policy).double(),
+                   torch.from_numpy(value).double(), torch.from_numpy(ube).double(), blocks, True)
+(w64[0] + w64[1] + w64[2]).backward()
 worst = []
 for k in tr.names:
     if "running_" in k:
         continue
-    g, tg = tr.tensor(k, L.GRAD), p[k].grad.numpy()
-    worst.append((float(np.abs(g - tg.reshape(g.shape)).max() / (np.abs(tg).max() + 1e-12)), k))
-for r, k in sorted(worst, reverse=True)[:6]:
-    print("grad rel err %.3e  %s" % (r, k))
+    g, tg, g64 = tr.tensor(k, L.GRAD), p[k].grad.numpy(), p64[k].grad.numpy()
+    scale = np.abs(g64).max() + 1e-30
+    worst.append((float(np.abs(g - tg.reshape(g.shape)).max() / scale), float(np.abs(g - g64.reshape(g.shape)).max() / scale),
+                  float(np.abs(tg - g64).max() / scale), k))
+print("relative to the float64 gradient's largest entry:  hip-vs-torch32   hip-vs-f64   torch32-vs-f64")
+for a, b, c, k in sorted(worst, reverse=True)[:8]:
+    print("  %.3e   %.3e   %.3e   %s" % (a, b, c, k))
+
+# where does the worst tensor differ?  A ReLU whose input is ~0 can land on either side of zero in two fp32
+# computations; that changes the gradient of exactly one output channel of the layer below it.
+a, b, c, k = sorted(worst, reverse=True)[0]
+g, g64 = tr.tensor(k, L.GRAD), p64[k].grad.numpy()
+bad = np.abs(g - g64.reshape(g.shape)) > 1e-3 * np.abs(g64).max()
+if g.ndim == 4:
+    print("%s: %d entries off by more than 1e-3 of the largest, in output channels %s" % (k, int(bad.sum()), sorted(set(np.nonzero(bad)[0].tolist()))[:10]))
