@@ -502,6 +502,11 @@ struct tz_trainer {
     float *part = nullptr, *loss_p = nullptr, *loss_v = nullptr, *loss_u = nullptr, *losses = nullptr;
     int pstride = 0;
     hipStream_t stream = nullptr;
+    // weight gradients run on a second stream beside the data-gradient chain (own im2col scratch, two dC slots)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_dc[2] = {nullptr, nullptr}, ev_w[2] = {nullptr, nullptr};
+    float* col2 = nullptr;
+    float* dC2 = nullptr;
     std::vector<void*> allocs;
 };
 
@@ -563,19 +568,20 @@ int launch_check(const char* what) {
 }
 
 int gemm(tz_trainer* t, bool at, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
-         int ldb, int ldc, bool accumulate) {
+         int ldb, int ldc, bool accumulate, hipStream_t st = nullptr) {
+    if (!st) st = t->stream;
     if (M % 64 || N % 64 || K % 32 || lda % 4 || ldb % 4) return tz_fail(TZ_EINVAL, "trainer gemm: unaligned shape");
     const dim3 grid(M / 64, N / 64);
     if (at)
-        gemm_f32_kernel<true><<<grid, 512, 0, t->stream>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
+        gemm_f32_kernel<true><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
     else
-        gemm_f32_kernel<false><<<grid, 512, 0, t->stream>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
+        gemm_f32_kernel<false><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
     return launch_check("gemm_f32");
 }
 
-int im2col(tz_trainer* t, const float* x, int C, int Kp) {
+int im2col(tz_trainer* t, const float* x, int C, int Kp, float* col = nullptr, hipStream_t st = nullptr) {
     const size_t total = (size_t)t->M * (Kp / 4);
-    im2col_kernel<<<(unsigned)((total + 255) / 256), 256, 0, t->stream>>>(x, t->col, t->M, t->n, C, Kp);
+    im2col_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st ? st : t->stream>>>(x, col ? col : t->col, t->M, t->n, C, Kp);
     return launch_check("im2col");
 }
 
@@ -677,30 +683,41 @@ int backward(tz_trainer* t, int train_ube) {
         const float* invstd = mean + FILTERS;
         const std::string bn = bn_name(t, l), cv = conv_name(t, l);
         if (second) skip = free_buf(da, nullptr);
+        const int slot = l & 1;
+        float* dc = slot ? t->dC2 : t->dC;
+        TZ_HIP(hipStreamWaitEvent(t->stream, t->ev_w[slot], 0));  // the weight gradient of layer l+2 has read this slot
         column_partials_kernel<<<dim3(FILTERS / 32, SPLITS), 256, 0, t->stream>>>(1, t->c[l], da, t->a[l], mean, invstd, M,
                                                                                   t->partial);
         bn_bwd_finish_kernel<<<1, FILTERS, 0, t->stream>>>(t->partial, M, gp(t, bn + ".weight"), gp(t, bn + ".bias"),
                                                            t->mean_dy, t->mean_dyx);
         bn_bwd_apply_kernel<<<(unsigned)((act + 255) / 256), 256, 0, t->stream>>>(
-            t->c[l], da, t->a[l], mean, invstd, pp(t, bn + ".weight"), t->mean_dy, t->mean_dyx, t->dC,
+            t->c[l], da, t->a[l], mean, invstd, pp(t, bn + ".weight"), t->mean_dy, t->mean_dyx, dc,
             second ? skip : nullptr, act);
         if ((rc = launch_check("batch norm backward"))) return rc;
+        TZ_HIP(hipEventRecord(t->ev_dc[slot], t->stream));
+        // weight gradient on the second stream: dW = im2col(input)^T x dc
         const float* in = l == 0 ? t->x0 : t->a[l - 1];
         const int C = l == 0 ? t->cin : FILTERS, Kp = l == 0 ? t->kp_in : 9 * FILTERS;
-        if ((rc = im2col(t, in, C, Kp))) return rc;
-        if ((rc = gemm(t, true, t->col, t->dC, gp(t, cv + ".weight"), nullptr, Kp, FILTERS, M, Kp, FILTERS, FILTERS, false)))
+        TZ_HIP(hipStreamWaitEvent(t->stream2, t->ev_dc[slot], 0));
+        if ((rc = im2col(t, in, C, Kp, t->col2, t->stream2))) return rc;
+        if ((rc = gemm(t, true, t->col2, dc, gp(t, cv + ".weight"), nullptr, Kp, FILTERS, M, Kp, FILTERS, FILTERS, false,
+                       t->stream2)))
             return rc;
+        TZ_HIP(hipEventRecord(t->ev_w[slot], t->stream2));
         if (l == 0) break;
         if (second) {  // gradient w.r.t. a[l-1] (the ReLU between the two SmallBlocks)
             float* out = free_buf(da, skip);
-            if ((rc = conv_dgrad(t, t->dC, FILTERS, pp(t, cv + ".weight"), FILTERS, out, false))) return rc;
+            if ((rc = conv_dgrad(t, dc, FILTERS, pp(t, cv + ".weight"), FILTERS, out, false))) return rc;
             da = out;
         } else {       // gradient w.r.t. the block input: through the first SmallBlock plus the skip connection
-            if ((rc = conv_dgrad(t, t->dC, FILTERS, pp(t, cv + ".weight"), FILTERS, skip, true))) return rc;
+            if ((rc = conv_dgrad(t, dc, FILTERS, pp(t, cv + ".weight"), FILTERS, skip, true))) return rc;
             da = skip;
             skip = nullptr;
         }
     }
+    // every weight gradient is in place before anything else (Adam, a read-back) runs on the main stream
+    TZ_HIP(hipStreamWaitEvent(t->stream, t->ev_w[0], 0));
+    TZ_HIP(hipStreamWaitEvent(t->stream, t->ev_w[1], 0));
     return TZ_OK;
 }
 
@@ -786,6 +803,8 @@ int tz_trainer_create(int board_n, int arch, int device_id, int blocks, int batc
         if ((rc = dalloc(t, &t->dA, act))) break;
         if ((rc = dalloc(t, &t->dB, act))) break;
         if ((rc = dalloc(t, &t->dC, act))) break;
+        if ((rc = dalloc(t, &t->dC2, act))) break;
+        if ((rc = dalloc(t, &t->col2, (size_t)t->M * 9 * FILTERS))) break;
         if ((rc = dalloc(t, &t->dskip, act))) break;
         if ((rc = dalloc(t, &t->pol, (size_t)t->M * t->np))) break;
         if ((rc = dalloc(t, &t->dpol, (size_t)t->M * t->np))) break;
@@ -802,7 +821,12 @@ int tz_trainer_create(int board_n, int arch, int device_id, int blocks, int batc
         if ((rc = dalloc(t, &t->loss_u, (size_t)batch))) break;
         if ((rc = dalloc(t, &t->losses, (size_t)4))) break;
     } while (0);
-    if (!rc && hipStreamCreate(&t->stream) != hipSuccess) rc = tz_fail(TZ_EDEVICE, "tz_trainer_create: stream");
+    if (!rc && (hipStreamCreate(&t->stream) != hipSuccess || hipStreamCreate(&t->stream2) != hipSuccess))
+        rc = tz_fail(TZ_EDEVICE, "tz_trainer_create: stream");
+    for (int i = 0; i < 2 && !rc; i++)
+        if (hipEventCreateWithFlags(&t->ev_dc[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&t->ev_w[i], hipEventDisableTiming) != hipSuccess)
+            rc = tz_fail(TZ_EDEVICE, "tz_trainer_create: event");
     if (!rc) {
         std::vector<uint8_t> groups(t->total / 1024, 0);
         for (const Param& p : t->params)
@@ -813,6 +837,11 @@ int tz_trainer_create(int board_n, int arch, int device_id, int blocks, int batc
     if (rc) {
         for (void* q : t->allocs) (void)hipFree(q);
         if (t->stream) (void)hipStreamDestroy(t->stream);
+        if (t->stream2) (void)hipStreamDestroy(t->stream2);
+        for (int i = 0; i < 2; i++) {
+            if (t->ev_dc[i]) (void)hipEventDestroy(t->ev_dc[i]);
+            if (t->ev_w[i]) (void)hipEventDestroy(t->ev_w[i]);
+        }
         delete t;
         return rc;
     }
@@ -824,8 +853,14 @@ int tz_trainer_destroy(tz_trainer* t) {
     if (!t) return TZ_OK;
     (void)hipSetDevice(t->device);
     (void)hipStreamSynchronize(t->stream);
+    (void)hipStreamSynchronize(t->stream2);
     for (void* q : t->allocs) (void)hipFree(q);
     (void)hipStreamDestroy(t->stream);
+    (void)hipStreamDestroy(t->stream2);
+    for (int i = 0; i < 2; i++) {
+        (void)hipEventDestroy(t->ev_dc[i]);
+        (void)hipEventDestroy(t->ev_w[i]);
+    }
     delete t;
     return TZ_OK;
 }
