@@ -87,7 +87,7 @@ class Net:
         h = C.c_void_p()
         check(self.lib.tz_net_create(n, arch, device, precision, blocks, C.byref(h)))
         self.h = h
-        self.arch, self.precision = arch, precision
+        self.arch, self.precision, self.blocks, self.device = arch, precision, blocks, device
         self.n = {ARCH_NET5: 5, ARCH_NET4_SIMHASH: 4, ARCH_NET6_SIMHASH: 6}.get(arch, n)
 
     def close(self):
@@ -125,7 +125,60 @@ class Net:
         blob = dumps_tzw(tensors)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         check(self.lib.tz_net_load_weights_mem(self.h, C.addressof(buf), len(blob)))
+        self._tensors = tensors   # the VarStore's host copy, for save / clone (not copied: callers hand over ownership)
         return self
+
+    @classmethod
+    def new(cls, arch=ARCH_NET5, seed=None, n=0, device=0, precision=PREC_BF16, blocks=0):
+        """Network::new(device, seed) (network/mod.rs:11): randomly initialised weights, tch's default initialisers."""
+        from . import weights as W
+
+        net = cls(arch=arch, n=n, device=device, precision=precision, blocks=blocks)
+        net.device, net.blocks = device, blocks
+        return net.load_tensors(W.init_weights(arch, n=n, blocks=blocks, seed=0 if seed is None else seed))
+
+    def save(self, path):
+        """Network::save (network/mod.rs:16-18): `.ot` = LibTorch archive as tch writes it, else the .tzw container."""
+        tensors = getattr(self, "_tensors", None)
+        if tensors is None:
+            raise TakzeroError(-6, "save: the network has no weights loaded through this object")
+        if str(path).endswith(".ot"):
+            from . import ot
+
+            ot.save_ot(path, tensors)
+        else:
+            from .weights import save_tzw
+
+            save_tzw(path, tensors)
+
+    def load_partial(self, path):
+        """Network::load_partial (network/mod.rs:30-35): variables missing from the file keep their current values;
+        returns their names (tch's VarStore::load_partial)."""
+        from . import ot
+        from .weights import load_tzw
+
+        have = getattr(self, "_tensors", None)
+        if have is None:
+            raise TakzeroError(-6, "load_partial: initialise the network first (Net.new or load)")
+        found = ot.load_ot(path) if str(path).endswith(".ot") else load_tzw(path)
+        merged = dict(have)
+        missing = [k for k in have if k not in found]
+        for k, v in found.items():
+            if k in merged and np.shape(v) == np.shape(merged[k]):
+                merged[k] = v
+            elif k in merged:
+                missing.append(k)
+        self.load_tensors(merged)
+        return missing
+
+    def clone(self, device=0):
+        """Network::clone(device) (network/mod.rs:37-44): the same weights on another GPU."""
+        tensors = getattr(self, "_tensors", None)
+        if tensors is None:
+            raise TakzeroError(-6, "clone: the network has no weights loaded through this object")
+        other = Net(arch=self.arch, n=self.n, device=device, precision=self.precision, blocks=getattr(self, "blocks", 0))
+        other.blocks = getattr(self, "blocks", 0)
+        return other.load_tensors(tensors)
 
     def policy_value_uncertainty(self, env_batch, actions_batch):
         """Agent::policy_value_uncertainty: returns (list of per-env logits arrays, values, variances)."""

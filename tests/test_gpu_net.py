@@ -160,3 +160,36 @@ def test_simhash_indices_counts_and_bitvec_file(oracle, tmp_path):
     assert np.array_equal(net2.policy_value_uncertainty(arr, acts)[2], var1)
     with pytest.raises(A.TakzeroError):
         net2.load_bitset(tmp_path / "missing.bin")
+
+
+def test_network_lifecycle_new_save_load_partial_clone(oracle, tmp_path):
+    """Network::{new, save, load, load_partial, clone} (network/mod.rs:10-45)."""
+    A = require_gpu()
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    try:
+        ot.build_writer()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    n, blocks = 4, 1
+    a = A.Net.new(arch=A.ARCH_TEST, seed=5, n=n, blocks=blocks)
+    states = O.states_array(random_positions(oracle, O, n, 4, 6, 3))
+    want = a.forward_raw(states)
+    a.save(tmp_path / "model_0000000.ot")
+    a.save(tmp_path / "model.tzw")
+    for path in ("model_0000000.ot", "model.tzw"):
+        b = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load(tmp_path / path)
+        assert all(np.array_equal(x, y) for x, y in zip(b.forward_raw(states), want)), path
+    c = a.clone(0)
+    assert all(np.array_equal(x, y) for x, y in zip(c.forward_raw(states), want))
+    # load_partial: a file without the policy head leaves that head as it was and reports it
+    other = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=6)
+    partial = {k: v for k, v in other.items() if not k.startswith("policy.")}
+    W.save_tzw(tmp_path / "partial.tzw", partial)
+    missing = a.load_partial(tmp_path / "partial.tzw")
+    assert sorted(missing) == ["policy.conv2d.bias", "policy.conv2d.weight"]
+    mixed = dict(other)
+    mixed.update({k: v for k, v in W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=5).items() if k.startswith("policy.")})
+    d = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(mixed)
+    assert all(np.array_equal(x, y) for x, y in zip(a.forward_raw(states), d.forward_raw(states)))
