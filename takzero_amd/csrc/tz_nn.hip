@@ -304,6 +304,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void conv_mfma_kernel(ConvArgs a) {  
 #pragma unroll
             for (int j = 0; j < RN; j++) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nslices = (a.cin_pad + 255) / 256;
+        // activation slices (256 input channels each) travel global -> registers -> LDS; the registers of slice s+1 are
+        // filled while slice s is being multiplied, so only the first slice's memory round trip is exposed
+        constexpr int NLOAD = FROM_STATE ? 1 : (LROWS * 32 + NT - 1) / NT;
+        uint4 stage[NLOAD];
+        auto fetch_slice = [&](int slice) {
+            const int cpr_s = min(256, a.cin_pad - slice * 256) / 8;
+            const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in) + (size_t)blockIdx.z * a.in_z + slice * 256;
+#pragma unroll
+            for (int i = 0; i < NLOAD; i++) {
+                const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+                stage[i] = make_uint4(0, 0, 0, 0);
+                if (row < valid_rows && ci < cpr_s) stage[i] = *reinterpret_cast<const uint4*>(in + (m0 + row) * a.in_stride + ci * 8);
+            }
+        };
+        if constexpr (!FROM_STATE) fetch_slice(0);
         for (int slice = 0; slice < nslices; slice++) {
             const int cs = min(256, a.cin_pad - slice * 256);
             const int kcs = cs / 32, cpr = cs / 8;
@@ -331,19 +346,43 @@ __global__ __launch_bounds__(NW * 64, OCC) void conv_mfma_kernel(ConvArgs a) {  
                     }
                 }
             } else {
-                const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
-                for (int id = tid; id < LROWS * cpr; id += NT) {
-                    const int row = id / cpr, ci = id % cpr;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (row < valid_rows)
-                        v = *reinterpret_cast<const uint4*>(in + (size_t)blockIdx.z * a.in_z + (m0 + row) * a.in_stride + slice * 256 + ci * 8);
-                    *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v;
+#pragma unroll
+                for (int i = 0; i < NLOAD; i++) {
+                    const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+                    if (row < LROWS && ci < cpr) *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = stage[i];
                 }
+                if (slice + 1 < nslices) fetch_slice(slice + 1);
             }
             __syncthreads();
             ex8 bnext[RN];
 #pragma unroll
             for (int j = 0; j < RN; j++) bnext[j] = wload(0, slice * 8, j);
+            if constexpr (TAPS == 1) {
+                // linear layers (the RND MLP): fragments of k-step kc+1 are loaded into the registers the MFMAs of
+                // k-step kc have just consumed, weights one k-step ahead
+                int abase[RT];
+                tap_bases<NB, RT, TAPS, LAYOUT>(yx, 0, lr, q, ZROW, abase);
+                ex8 av[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                for (int kc = 0; kc < kcs; kc++) {
+                    ex8 bcur[RN];
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bcur[j] = bnext[j];
+                    if (kc + 1 < kcs) {
+#pragma unroll
+                        for (int j = 0; j < RN; j++) bnext[j] = wload(0, slice * 8 + kc + 1, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                        for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(bcur[j], av[rt], acc[rt][j]);
+                        if (kc + 1 < kcs) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1) * KSTEP);
+                    }
+                }
+                continue;
+            }
             for (int tap = 0; tap < TAPS; tap++) {
                 int abase[RT];
                 tap_bases<NB, RT, TAPS, LAYOUT>(yx, tap, lr, q, ZROW, abase);
