@@ -2,13 +2,13 @@
 // three losses, backward and Adam (learn/src/main.rs:376-423; graph net5.rs:44-191, residual.rs:13-63).
 //
 // The reference trains in fp32 through LibTorch; so does this: every contraction is an fp32 MFMA GEMM
-// (v_mfma_f32_32x32x2_f32) over explicit im2col matrices — at the reference's batch of 128 positions a
-// step is 0.46 TFLOP, so the layout is chosen for exactness and simplicity, not for the last TFLOP/s:
+// (v_mfma_f32_32x32x2_f32) whose A operand is the im2col view of an NHWC tensor, gathered by the tile loader
+// (no col matrix exists) — at the reference's batch of 128 positions a step is 0.46 TFLOP:
 //
 //   activations   NHWC fp32  [M = batch*n*n][256]            (everything of one step stays resident)
 //   conv weights  GEMM layout [K = 9*cin (padded to 64)][cout (padded to 64)], k = tap*cin + ci
-//   forward       col = im2col(x);  c = col x W;  BatchNorm with batch statistics;  ReLU (+ skip)
-//   backward      dW = col^T x dc  (A-transposed GEMM);  dx = im2col(dc) x W'  with W' = taps mirrored, ci/co swapped
+//   forward       c = im2col(x) x W;  BatchNorm with batch statistics;  ReLU (+ skip)
+//   backward      dW = im2col(x)^T x dc  (A-transposed GEMM);  dx = im2col(dc) x W'  with W' = taps mirrored, ci/co swapped
 //   parameters, gradients and the two Adam moments live in four parallel arenas; one Adam launch per step.
 #include <math.h>
 #include <string.h>
@@ -37,10 +37,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // of its waves owning a 32x32 quadrant, so every SIMD has two waves to interleave; the two partial tiles are added
 // through LDS at the end (fixed order: deterministic).  Slabs are double buffered in LDS (one barrier per step) and
 // the next pair is fetched into registers while the MFMAs of the current one run.
-template <bool AT>
+//
+// GATHER: A is not a stored matrix but the im2col view of an NHWC tensor x [pixels][gc]: A(pixel, tap*gc + c) =
+// x[(board, y + tap/3 - 1, x + tap%3 - 1)][c], zero off the board and for k >= 9*gc (the K padding).  The loader
+// computes that address itself (4 consecutive channels per thread), so no col matrix is ever written or read.
+template <bool AT, bool GATHER>
 __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const float* __restrict__ bias, int K,
-                                                       int lda, int ldb, int ldc, int accumulate) {
+                                                       int lda, int ldb, int ldc, int accumulate, int gn, int gc) {
     __shared__ float As[2][2][16][68];  // [buffer][group][k][m]
     __shared__ float Bs[2][2][16][68];
     const int g = threadIdx.x >> 8, t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
@@ -51,10 +55,45 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
     const float* ap = AT ? A + (size_t)(16 * g + ak) * lda + m0 + am : A + (m0 + am) * lda + 16 * g + ak;
     const float* bp = B + (size_t)(16 * g + bk) * ldb + n0 + bn;
     const size_t astep = AT ? (size_t)32 * lda : 32, bstep = (size_t)32 * ldb;
+    // gather state, kept incrementally (no division in the loop).  !AT: this thread's pixel is fixed (row m0+am), its
+    // k = tap*gc + c advances by 32 per step.  AT: its 4 k-indices are fixed (m0+am..+3 = one tap, 4 channels), its
+    // pixel advances by 32 per step.
+    const int gnn = gn * gn;
+    const int inv_n = 65536 / (gn > 0 ? gn : 1) + 1;   // q / gn == (q * inv_n) >> 16 for q < 64
+    int g_b = 0, g_lp = 0, g_tap = 0, g_c = 0;          // board, pixel inside the board, tap, channel
+    if (GATHER) {
+        const int pix = AT ? 16 * g + ak : (int)m0 + am, k = AT ? (int)m0 + am : 16 * g + ak;
+        g_b = pix / gnn;
+        g_lp = pix - g_b * gnn;
+        g_tap = k / gc;            // >= 9 marks the K padding
+        g_c = k - g_tap * gc;
+    }
+    auto gather = [&]() -> float4 {
+        if (g_tap >= 9) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int py = (g_lp * inv_n) >> 16, t3 = (g_tap * 11) >> 5;   // tap / 3
+        const int y = py + t3 - 1, x = g_lp - py * gn + (g_tap - 3 * t3) - 1;
+        if (y < 0 || y >= gn || x < 0 || x >= gn) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *(const float4*)(A + ((size_t)g_b * gnn + y * gn + x) * gc + g_c);
+    };
+    auto gather_advance = [&]() {
+        if (AT) {
+            g_lp += 32;
+            while (g_lp >= gnn) {
+                g_lp -= gnn;
+                g_b++;
+            }
+        } else {
+            g_c += 32;
+            while (g_c >= gc) {
+                g_c -= gc;
+                g_tap++;
+            }
+        }
+    };
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
-    float4 ra = *(const float4*)ap, rb = *(const float4*)bp;
+    float4 ra = GATHER ? gather() : *(const float4*)ap, rb = *(const float4*)bp;
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += 32, buf ^= 1) {
         if (AT) {
@@ -68,9 +107,14 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
         *(float4*)&Bs[buf][g][bk][bn] = rb;
         __syncthreads();
         if (k0 + 32 < K) {
-            ap += astep;
             bp += bstep;
-            ra = *(const float4*)ap;
+            if (GATHER) {
+                gather_advance();
+                ra = gather();
+            } else {
+                ap += astep;
+                ra = *(const float4*)ap;
+            }
             rb = *(const float4*)bp;
         }
 #pragma unroll
@@ -98,21 +142,6 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
         if (accumulate) v += C[m * ldc + n];
         C[m * ldc + n] = v;
     }
-}
-
-// col[m][k], k = tap*C + c (zero for k >= 9*C and outside the board); x is [M][C] NHWC. One thread per 4 floats.
-__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int M, int n, int C, int Kp) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int kq = Kp / 4;
-    if (idx >= (size_t)M * kq) return;
-    const int m = (int)(idx / kq), k = (int)(idx % kq) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < 9 * C) {
-        const int tap = k / C, c = k % C, nn = n * n;
-        const int b = m / nn, px = m % nn, y = px / n + tap / 3 - 1, xx = px % n + tap % 3 - 1;
-        if (y >= 0 && y < n && xx >= 0 && xx < n) v = *(const float4*)(x + ((size_t)b * nn + y * n + xx) * C + c);
-    }
-    *(float4*)(col + (size_t)m * Kp + k) = v;
 }
 
 // W'[(tap'*Co + co)][ci] = W[((8-tap')*Ci + ci)][co]: the weight matrix of the data gradient.  ldw / ldo = row strides.
@@ -492,7 +521,6 @@ struct tz_trainer {
     float* stats = nullptr;              // [layers][2][256] mean, invstd
     double* partial = nullptr;           // [SPLITS][256][2]
     float *mean_dy = nullptr, *mean_dyx = nullptr;
-    float* col = nullptr;                // [M][max K]
     float* wmirror = nullptr;            // [max K'][256]
     float *dA = nullptr, *dB = nullptr, *dC = nullptr, *dskip = nullptr;  // [M][256] gradient ping-pong
     float *pol = nullptr, *dpol = nullptr;                                // [M][np]
@@ -502,10 +530,9 @@ struct tz_trainer {
     float *part = nullptr, *loss_p = nullptr, *loss_v = nullptr, *loss_u = nullptr, *losses = nullptr;
     int pstride = 0;
     hipStream_t stream = nullptr;
-    // weight gradients run on a second stream beside the data-gradient chain (own im2col scratch, two dC slots)
+    // weight gradients run on a second stream beside the data-gradient chain (two dC slots)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_dc[2] = {nullptr, nullptr}, ev_w[2] = {nullptr, nullptr};
-    float* col2 = nullptr;
     float* dC2 = nullptr;
     std::vector<void*> allocs;
 };
@@ -568,21 +595,23 @@ int launch_check(const char* what) {
 }
 
 int gemm(tz_trainer* t, bool at, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
-         int ldb, int ldc, bool accumulate, hipStream_t st = nullptr) {
+         int ldb, int ldc, bool accumulate, hipStream_t st = nullptr, int gather_c = 0) {
     if (!st) st = t->stream;
-    if (M % 64 || N % 64 || K % 32 || lda % 4 || ldb % 4) return tz_fail(TZ_EINVAL, "trainer gemm: unaligned shape");
+    if (M % 64 || N % 64 || K % 32 || lda % 4 || ldb % 4 || gather_c % 4)
+        return tz_fail(TZ_EINVAL, "trainer gemm: unaligned shape");
     const dim3 grid(M / 64, N / 64);
-    if (at)
-        gemm_f32_kernel<true><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
-    else
-        gemm_f32_kernel<false><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, accumulate ? 1 : 0);
+    const int acc = accumulate ? 1 : 0;
+    if (gather_c) {   // A = im2col view of the NHWC tensor at `A` with gather_c channels
+        if (at)
+            gemm_f32_kernel<true, true><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, t->n, gather_c);
+        else
+            gemm_f32_kernel<false, true><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, t->n, gather_c);
+    } else if (at) {
+        gemm_f32_kernel<true, false><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, 0, 0);
+    } else {
+        gemm_f32_kernel<false, false><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, 0, 0);
+    }
     return launch_check("gemm_f32");
-}
-
-int im2col(tz_trainer* t, const float* x, int C, int Kp, float* col = nullptr, hipStream_t st = nullptr) {
-    const size_t total = (size_t)t->M * (Kp / 4);
-    im2col_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st ? st : t->stream>>>(x, col ? col : t->col, t->M, t->n, C, Kp);
-    return launch_check("im2col");
 }
 
 int forward(tz_trainer* t) {
@@ -593,9 +622,8 @@ int forward(tz_trainer* t) {
     for (int l = 0; l < t->layers; l++) {
         const float* in = l == 0 ? t->x0 : t->a[l - 1];
         const int C = l == 0 ? t->cin : FILTERS, Kp = l == 0 ? t->kp_in : 9 * FILTERS;
-        if ((rc = im2col(t, in, C, Kp))) return rc;
-        if ((rc = gemm(t, false, t->col, pp(t, conv_name(t, l) + ".weight"), t->c[l], nullptr, M, FILTERS, Kp, Kp, FILTERS,
-                       FILTERS, false)))
+        if ((rc = gemm(t, false, in, pp(t, conv_name(t, l) + ".weight"), t->c[l], nullptr, M, FILTERS, Kp, Kp, FILTERS,
+                       FILTERS, false, nullptr, C)))
             return rc;
         float* mean = t->stats + (size_t)l * 2 * FILTERS;
         float* invstd = mean + FILTERS;
@@ -610,9 +638,8 @@ int forward(tz_trainer* t) {
         if ((rc = launch_check("batch norm forward"))) return rc;
     }
     const float* T = t->a[t->layers - 1];
-    if ((rc = im2col(t, T, FILTERS, 9 * FILTERS))) return rc;
-    if ((rc = gemm(t, false, t->col, pp(t, "policy.conv2d.weight"), t->pol, pp(t, "policy.conv2d.bias"), M, t->np,
-                   9 * FILTERS, 9 * FILTERS, t->np, t->np, false)))
+    if ((rc = gemm(t, false, T, pp(t, "policy.conv2d.weight"), t->pol, pp(t, "policy.conv2d.bias"), M, t->np,
+                   9 * FILTERS, 9 * FILTERS, t->np, t->np, false, nullptr, FILTERS)))
         return rc;
     heads_fwd_kernel<<<t->batch, 64, 0, t->stream>>>(T, pp(t, "value.conv2d.weight"), pp(t, "value.conv2d.bias"),
                                                     pp(t, "value.linear.weight"), pp(t, "value.linear.bias"),
@@ -628,8 +655,7 @@ int conv_dgrad(tz_trainer* t, const float* dc, int Cd, const float* W, int ldw, 
     const size_t total = (size_t)9 * Cd * FILTERS;
     mirror_weights_kernel<<<(unsigned)((total + 255) / 256), 256, 0, t->stream>>>(W, t->wmirror, FILTERS, Cd, ldw, FILTERS);
     if ((rc = launch_check("mirror weights"))) return rc;
-    if ((rc = im2col(t, dc, Cd, 9 * Cd))) return rc;
-    return gemm(t, false, t->col, t->wmirror, out, nullptr, t->M, FILTERS, 9 * Cd, 9 * Cd, FILTERS, FILTERS, accumulate);
+    return gemm(t, false, dc, t->wmirror, out, nullptr, t->M, FILTERS, 9 * Cd, 9 * Cd, FILTERS, FILTERS, accumulate, nullptr, Cd);
 }
 
 int backward(tz_trainer* t, int train_ube) {
@@ -660,9 +686,8 @@ int backward(tz_trainer* t, int train_ube) {
         if ((rc = launch_check("head gradients"))) return rc;
     }
     // policy conv: weight / bias gradient, and its data gradient added to the value head's (already in dA)
-    if ((rc = im2col(t, T, FILTERS, 9 * FILTERS))) return rc;
-    if ((rc = gemm(t, true, t->col, t->dpol, gp(t, "policy.conv2d.weight"), nullptr, 9 * FILTERS, t->np, M, 9 * FILTERS, t->np,
-                   t->np, false)))
+    if ((rc = gemm(t, true, T, t->dpol, gp(t, "policy.conv2d.weight"), nullptr, 9 * FILTERS, t->np, M, 9 * FILTERS, t->np,
+                   t->np, false, nullptr, FILTERS)))
         return rc;
     column_sum_kernel<<<(t->np + 31) / 32, 256, 0, t->stream>>>(t->dpol, M, t->np, t->np, gp(t, "policy.conv2d.bias"));
     if ((rc = launch_check("policy bias gradient"))) return rc;
@@ -699,9 +724,8 @@ int backward(tz_trainer* t, int train_ube) {
         const float* in = l == 0 ? t->x0 : t->a[l - 1];
         const int C = l == 0 ? t->cin : FILTERS, Kp = l == 0 ? t->kp_in : 9 * FILTERS;
         TZ_HIP(hipStreamWaitEvent(t->stream2, t->ev_dc[slot], 0));
-        if ((rc = im2col(t, in, C, Kp, t->col2, t->stream2))) return rc;
-        if ((rc = gemm(t, true, t->col2, dc, gp(t, cv + ".weight"), nullptr, Kp, FILTERS, M, Kp, FILTERS, FILTERS, false,
-                       t->stream2)))
+        if ((rc = gemm(t, true, in, dc, gp(t, cv + ".weight"), nullptr, Kp, FILTERS, M, Kp, FILTERS, FILTERS, false,
+                       t->stream2, C)))
             return rc;
         TZ_HIP(hipEventRecord(t->ev_w[slot], t->stream2));
         if (l == 0) break;
@@ -798,13 +822,11 @@ int tz_trainer_create(int board_n, int arch, int device_id, int blocks, int batc
         if ((rc = dalloc(t, &t->partial, (size_t)SPLITS * FILTERS * 2))) break;
         if ((rc = dalloc(t, &t->mean_dy, (size_t)FILTERS))) break;
         if ((rc = dalloc(t, &t->mean_dyx, (size_t)FILTERS))) break;
-        if ((rc = dalloc(t, &t->col, (size_t)t->M * kmax))) break;
         if ((rc = dalloc(t, &t->wmirror, (size_t)kmax * FILTERS))) break;
         if ((rc = dalloc(t, &t->dA, act))) break;
         if ((rc = dalloc(t, &t->dB, act))) break;
         if ((rc = dalloc(t, &t->dC, act))) break;
         if ((rc = dalloc(t, &t->dC2, act))) break;
-        if ((rc = dalloc(t, &t->col2, (size_t)t->M * 9 * FILTERS))) break;
         if ((rc = dalloc(t, &t->dskip, act))) break;
         if ((rc = dalloc(t, &t->pol, (size_t)t->M * t->np))) break;
         if ((rc = dalloc(t, &t->dpol, (size_t)t->M * t->np))) break;
