@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--capacity", type=int, default=0)
+    ap.add_argument("--search", choices=["puct", "gumbel"], default="puct",
+                    help="puct = the north star's PUCT + Dirichlet loop (default); gumbel = what the reference's selfplay "
+                         "binary runs today (sequential halving, 64 sampled actions; use --sims 768 for its budget)")
     ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16",
                     help="16-bit storage type of the MFMA path (same kernels, same rate; f16 is within 1e-3 of fp32)")
     args = ap.parse_args()
@@ -142,7 +145,7 @@ def main():
     net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_F16 if args.precision == "f16" else A.PREC_BF16)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
-    sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank)
+    sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank, search=args.search, sampled_actions=64)
     dev = "cuda:%d" % local_rank if backend == "nccl" else "cpu"
 
     def barrier():
@@ -193,8 +196,9 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic (random-init net5 weights seed 123, random symmetric openings)",
-            "config": {"workload": "5x5 Tak self-play, %d concurrent games/GPU, %d sims/move, PUCT+Dirichlet, net5 (BASELINE configs[1])"
-                                   % (args.games, args.sims),
+            "config": {"workload": "5x5 Tak self-play, %d concurrent games/GPU, %d sims/move, %s, net5 (BASELINE configs[1])"
+                                   % (args.games, args.sims,
+                                      "PUCT+Dirichlet" if args.search == "puct" else "Gumbel sequential halving k=64"),
                        "games_per_gpu": args.games, "sims_per_move": args.sims, "parallelism": "shard%d" % world},
             "selfplay_positions_per_s": positions / dt_max,
             "nn_leaf_evals_per_s": evals / dt_max,
