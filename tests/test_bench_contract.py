@@ -1,0 +1,35 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (a reduced workload here; the default run is the
+driver's).  Guards the contract, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--search", "gumbel", "--sims", "384"], ["--precision", "f16"]])
+def test_bench_line_has_the_contract_fields(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--games", "256",
+           "--sims", "48", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    out = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict)):
+        assert isinstance(out[key], typ), (key, out[key])
+    assert out["vs_baseline"] is None and out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["metric"] == "mcts_simulations_per_s" and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    expect = "f16" if "f16" in extra else "bf16"
+    assert out["dtype"] == expect
