@@ -33,3 +33,22 @@ def test_bench_line_has_the_contract_fields(extra):
     assert out["value"] > 0 and out["ms_per_step"] > 0
     expect = "f16" if "f16" in extra else "bf16"
     assert out["dtype"] == expect
+
+
+@pytest.mark.gpu
+def test_two_rank_launch_as_the_driver_does_it():
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...: both ranks on this box's one GPU with
+    the target exchange over gloo (TZ_BENCH_BACKEND / TZ_BENCH_DEVICE are the rehearsal switches; on the 8-GPU node the
+    default is RCCL, one rank per GPU).  Rank 0 prints the one line; value aggregates both ranks."""
+    env = dict(os.environ, TZ_BENCH_BACKEND="gloo", TZ_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--games", "128", "--sims", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-800:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    # whole-job aggregate: 2 ranks x 128 games x 33 simulate calls per move x 2 timed moves
+    assert abs(out["value"] * out["ms_per_step"] * 2 / 1000.0 - 2 * 128 * 33 * 2) < 0.02 * 2 * 128 * 33 * 2
