@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--search", choices=["puct", "gumbel"], default="puct",
                     help="puct = the north star's PUCT + Dirichlet loop (default); gumbel = what the reference's selfplay "
                          "binary runs today (sequential halving, 64 sampled actions; use --sims 768 for its budget)")
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="native = the self-play outer loop in csrc/tz_host.cpp (tz_selfplay_*); python = its mirror in "
+                         "takzero_amd/selfplay.py")
     ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16",
                     help="16-bit storage type of the MFMA path (same kernels, same rate; f16 is within 1e-3 of fp32)")
     args = ap.parse_args()
@@ -145,7 +148,10 @@ def main():
     net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_F16 if args.precision == "f16" else A.PREC_BF16)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
-    sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank, search=args.search, sampled_actions=64)
+    if args.driver == "native":
+        sp = SP.NativeSelfPlay(mcts, args.sims, seed=0, shard=rank, search=args.search, sampled_actions=64)
+    else:
+        sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank, search=args.search, sampled_actions=64)
     dev = "cuda:%d" % local_rank if backend == "nccl" else "cpu"
 
     def barrier():
@@ -155,17 +161,27 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def one_move():
+        """One outer-loop iteration + the exchange of the finished targets (every rank ends up with all of them)."""
+        if args.driver == "native":
+            sp.play_move()
+            lines = sp.take_text(0)          # target lines finished this move, as learn reads them
+            sp.take_text(1)
+            if dist is not None:
+                lines = SP.all_gather_bytes(lines, dev)
+            return lines.count(b"\n")
+        t, _r = sp.play_move()
+        return len(SP.all_gather_targets(t, N_BOARD, dev) if dist is not None else t)
+
     gathered = 0
     for _ in range(args.warmup):
-        t, _r = sp.play_move()
-        gathered += len(SP.all_gather_targets(t, N_BOARD, dev) if dist is not None else t)
+        gathered += one_move()
     barrier()
     mcts.profile(reset=2 if args.no_profile else 1)
     sims0, evals0 = mcts.counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        t, _r = sp.play_move()
-        gathered += len(SP.all_gather_targets(t, N_BOARD, dev) if dist is not None else t)
+        gathered += one_move()
     barrier()
     dt = time.perf_counter() - t0
     sims1, evals1 = mcts.counters()
@@ -203,6 +219,7 @@ def main():
             "selfplay_positions_per_s": positions / dt_max,
             "nn_leaf_evals_per_s": evals / dt_max,
             "targets_gathered": gathered,
+            "host_driver": "native (csrc/tz_host.cpp)" if args.driver == "native" else "python (takzero_amd/selfplay.py)",
         }
         if not args.no_profile and prof["conv_launches"]:
             per_launch_positions = (evals1 - evals0) / max(1.0, (sims1 - sims0) / args.games)

@@ -158,6 +158,8 @@ int tz_net_save_bitset(tz_net* net, const char* path);
 int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int half_komi,
                      int node_capacity, tz_search** out);
 int tz_search_destroy(tz_search* s);
+/* BATCH_SIZE, N, HALF_KOMI of the handle and the widest child list it can hold */
+int tz_search_shape(tz_search* s, int* batch_out, int* board_n_out, int* half_komi_out, int* max_actions_out);
 /* nodes_and_envs_mut: overwrite envs and reset their trees (reanalyze/src/main.rs:159-165). */
 int tz_search_set_positions(tz_search* s, int count, const int32_t* game_idx, const tz_state* states);
 int tz_search_get_positions(tz_search* s, tz_state* states_out /*[batch]*/);
@@ -224,6 +226,24 @@ int tz_search_sync(tz_search* s);
  * launch count since the last reset; used by bench.py for the roofline line. */
 int tz_search_profile(tz_search* s, int reset, double* conv_ms, uint64_t* conv_launches,
                       double* tree_ms, uint64_t* steps);
+
+/* ---------- selfplay::main above the search (selfplay/src/main.rs:63-387), native host code (csrc/tz_host.cpp) ----------
+ * The outer loop of the reference's selfplay binary: search, move choice, take_a_step, restart_envs_and_complete_targets,
+ * target / replay lines, buffer_lengths.txt back-pressure, append-only files.  Draws (openings, Dirichlet, Gumbel, early
+ * move sampling) come from one seeded generator per (seed, shard).
+ * search_kind: 0 PUCT + Dirichlet (:127-136), 1 Gumbel sequential halving (:138-153), 2 uniformly random moves
+ * (learn's pre-training games, learn/src/main.rs:437-445).  exploration: cargo feature of that name (:79-86). */
+typedef struct tz_selfplay tz_selfplay;
+int tz_selfplay_create(tz_search* search, int sims_per_move, uint64_t seed, int shard, int search_kind, int sampled_actions,
+                       int exploration, tz_selfplay** out);
+int tz_selfplay_destroy(tz_selfplay* sp);
+int tz_selfplay_play_move(tz_selfplay* sp);
+int tz_selfplay_counters(tz_selfplay* sp, uint64_t* moves_out, uint64_t* targets_out, uint64_t* replays_out);
+/* which: 0 target lines, 1 replay lines, 2 exploration replay lines finished since the last call */
+int tz_selfplay_take_text(tz_selfplay* sp, int which, char* out, uint64_t cap, uint64_t* size_out);
+/* the directory loop; reload(user) is called before every move (Net::load of model_latest, :107-121), may be NULL */
+int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_buffer_len, const char* suffix,
+                    int (*reload)(void*), void* reload_user, double wait_limit_s);
 
 /* ---------- Target lines in bulk (impl Display / FromStr for Target, target.rs:56-73, 99-143) ----------
  * "{tps};{value};{ube};{move}:{p},...\n" with Rust's `Display for f32`.  moves / policy are [count][amax]. */

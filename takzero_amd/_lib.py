@@ -32,7 +32,9 @@ SYMBOLS = [
     "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_search_terminal_details", "tz_search_play_moves",
     "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
     "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
-    "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each",
+    "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
+    "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
+    "tz_selfplay_run",
 ]
 
 _lib = None
@@ -103,6 +105,13 @@ def load():
     lib.tz_format_targets.argtypes = [ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.tz_parse_targets.argtypes = [vp, C.c_uint64, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    lib.tz_search_shape.argtypes = [vp] + [C.POINTER(ci)] * 4
+    lib.tz_selfplay_create.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, ci, C.POINTER(vp)]
+    lib.tz_selfplay_destroy.argtypes = [vp]
+    lib.tz_selfplay_play_move.argtypes = [vp]
+    lib.tz_selfplay_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 3
+    lib.tz_selfplay_take_text.argtypes = [vp, ci, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.tz_selfplay_run.argtypes = [vp, C.c_char_p, ci, ci, C.c_char_p, vp, vp, C.c_double]
     lib.tz_trainer_create.argtypes = [ci, ci, ci, ci, ci, cf, C.POINTER(vp)]
     lib.tz_trainer_destroy.argtypes = [vp]
     lib.tz_trainer_tensor_count.argtypes = [vp]

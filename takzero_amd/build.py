@@ -11,6 +11,7 @@ ARCH = "gfx950"
 # no FMA contraction there.  The network kernels keep the default (contraction on).
 UNITS = [
     ("tz_text.cpp", ["-ffp-contract=off"]),
+    ("tz_host.cpp", ["-ffp-contract=off"]),
     ("tz_tree.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_capi.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_nn.hip", []),

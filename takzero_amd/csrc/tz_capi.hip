@@ -397,6 +397,15 @@ int tz_search_root_children(tz_search* s, int amax, uint16_t* move_idx, uint32_t
     return TZ_OK;
 }
 
+int tz_search_shape(tz_search* s, int* batch_out, int* board_n_out, int* half_komi_out, int* max_actions_out) {
+    if (!s) return tz_fail(TZ_EINVAL, "tz_search_shape: null handle");
+    if (batch_out) *batch_out = s->d.batch;
+    if (board_n_out) *board_n_out = s->d.n;
+    if (half_komi_out) *half_komi_out = s->d.half_komi;
+    if (max_actions_out) *max_actions_out = s->d.max_actions;
+    return TZ_OK;
+}
+
 int tz_search_select_best_actions(tz_search* s, uint16_t* actions_out) {
     if (!s || !actions_out) return tz_fail(TZ_EINVAL, "tz_search_select_best_actions: null argument");
     TZ_HIP(hipSetDevice(s->device));

@@ -1,0 +1,546 @@
+// tz_host.cpp — the host side of the reference's `selfplay` binary above the search ABI, in native code:
+// the outer loop of selfplay::main (selfplay/src/main.rs:63-205), take_a_step (:238-258),
+// restart_envs_and_complete_targets (:263-329), save_targets_to_file / save_replays_to_file (:332-366) and
+// read_buffer_lengths (:371-387).  The reference is compiled code and so is this; takzero_amd/selfplay.py is the same
+// driver in Python, kept because the tests also run it over the CPU oracle.
+//
+// Randomness (openings, Dirichlet / Gumbel samples, early-ply move sampling) is drawn here from one seeded
+// std::mt19937_64 per shard and handed to the search as input, exactly as the Python driver does with numpy.
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tz_engine.h"
+#include "tz_math.h"
+
+namespace {
+
+constexpr float NOISE_ALPHA = 0.05f;          // selfplay/src/main.rs:39
+constexpr float NOISE_RATIO = 0.2f;           // selfplay/src/main.rs:40
+constexpr int WEIGHTED_RANDOM_PLIES = 10;     // selfplay/src/main.rs:38
+constexpr float BETA = 0.25f;                 // selfplay/src/main.rs:41
+constexpr uint32_t SAMPLE_THRESHOLD = 32;     // batched.rs:175
+constexpr float ALLOWED_EVAL_DROP = 0.5f;     // batched.rs:176
+
+struct MoveRecord {  // IncompleteTarget for every game of the shard at one move (selfplay/src/main.rs:230-236)
+    std::vector<tz_state> states;
+    std::vector<uint16_t> moves;   // [B][width]
+    std::vector<float> pol;        // [B][width]
+    std::vector<float> ube;        // [B]
+    std::vector<uint32_t> nchild;  // [B]
+    std::vector<uint8_t> stepped;  // [B]
+    std::vector<uint16_t> actions; // [B]
+    int width = 0;
+};
+
+// total order of Eval as one double (eval.rs:138-163): Loss(p) < values / draws < Win(p)
+double eval_key(uint8_t tag, uint32_t bits) {
+    switch (tag) {
+        case TZ_EVAL_LOSS: return -1e9 + (double)bits;
+        case TZ_EVAL_WIN: return 1e9 - (double)bits;
+        case TZ_EVAL_DRAW: return (double)(-0.05f) - (double)bits * 1e-12;
+        default: return (double)tz_bits_to_float(bits);
+    }
+}
+
+float eval_to_f32(uint8_t tag, uint32_t ply) {  // impl From<Eval> for f32 (eval.rs:95-105) for proven results
+    const float base = tz_powif(TZ_DISCOUNT, (int)ply);
+    return base * (tag == TZ_EVAL_WIN ? 1.0f : tag == TZ_EVAL_LOSS ? -1.0f : 0.0f);
+}
+
+const char* result_string(int reason, int winner) {  // takparse GameResult (target.rs:226-230)
+    if (winner == 2) return "1/2-1/2";
+    if (reason == 1) return winner == 0 ? "R-0" : "0-R";
+    return winner == 0 ? "F-0" : "0-F";
+}
+
+}  // namespace
+
+struct tz_selfplay {
+    tz_search* search = nullptr;
+    int B = 0, n = 0, half_komi = 0, amax = 0;
+    int sims = 0, kind = 0, k = 64;
+    std::vector<float> betas;
+    std::mt19937_64 rng;
+    std::deque<MoveRecord> history;
+    int64_t history_base = 0, moves_played = 0;
+    std::vector<int64_t> game_start;
+    std::vector<tz_state> start_states;
+    // finished work, as text (drained by tz_selfplay_take_text or appended to files by the run loop)
+    std::string targets_text, replays_text, exploration_text;
+    uint64_t n_targets = 0, n_replays = 0, positions = 0;
+    // scratch
+    std::vector<tz_root_info> info;
+    std::vector<uint16_t> c_moves, actions, best;
+    std::vector<uint32_t> c_visits, c_bits;
+    std::vector<uint8_t> c_tag;
+    std::vector<float> noise, gumbel, pol, ube;
+    std::vector<int32_t> choice;
+    std::vector<int8_t> term, reason;
+    std::vector<uint8_t> winner;
+    // completed targets of one move, columnar, for tz_format_targets
+    std::vector<tz_state> t_states;
+    std::vector<uint16_t> t_moves;
+    std::vector<float> t_pol, t_value, t_ube;
+    std::vector<int32_t> t_n;
+};
+
+namespace {
+
+int fetch_children(tz_selfplay* sp, int* width_out) {
+    int rc = tz_search_root_info(sp->search, sp->info.data());
+    if (rc) return rc;
+    int w = 1;
+    for (int g = 0; g < sp->B; g++) w = std::max(w, (int)sp->info[g].n_children);
+    const size_t cells = (size_t)sp->B * w;
+    sp->c_moves.resize(cells);
+    sp->c_visits.resize(cells);
+    sp->c_tag.resize(cells);
+    sp->c_bits.resize(cells);
+    *width_out = w;
+    return tz_search_root_children(sp->search, w, sp->c_moves.data(), sp->c_visits.data(), sp->c_tag.data(), sp->c_bits.data(),
+                                   nullptr, nullptr, nullptr);
+}
+
+// BatchedMCTS::select_actions_in_selfplay (batched.rs:165-183) / Node::select_selfplay_action (node/mod.rs:170-207)
+int select_actions_in_selfplay(tz_selfplay* sp, std::vector<uint16_t>& out) {
+    int rc = tz_search_select_best_actions(sp->search, sp->best.data());
+    if (rc) return rc;
+    out = sp->best;
+    int w = 0;
+    if ((rc = fetch_children(sp, &w))) return rc;
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    std::vector<double> weight(w);
+    for (int g = 0; g < sp->B; g++) {
+        const tz_root_info& ri = sp->info[g];
+        const int nc = (int)ri.n_children;
+        if (ri.ply >= WEIGHTED_RANDOM_PLIES || ri.eval_tag != TZ_EVAL_VALUE || nc == 0) continue;
+        const size_t o = (size_t)g * w;
+        int bi = 0;
+        double best_key = eval_key(sp->c_tag[o], sp->c_bits[o]);
+        for (int i = 1; i < nc; i++) {
+            const double key = eval_key(sp->c_tag[o + i], sp->c_bits[o + i]);
+            if (key < best_key) {
+                best_key = key;
+                bi = i;
+            }
+        }
+        // best_eval.map(|x| x + allowed_eval_drop): only a Value moves
+        const double limit = sp->c_tag[o + bi] == TZ_EVAL_VALUE
+                                 ? (double)(tz_bits_to_float(sp->c_bits[o + bi]) + ALLOWED_EVAL_DROP)
+                                 : best_key;
+        double total = 0.0;
+        for (int i = 0; i < nc; i++) {
+            const bool ok = sp->c_visits[o + i] >= SAMPLE_THRESHOLD && sp->c_tag[o + i] != TZ_EVAL_WIN &&
+                            eval_key(sp->c_tag[o + i], sp->c_bits[o + i]) <= limit;
+            weight[i] = ok ? (double)sp->c_visits[o + i] : 0.0;
+            total += weight[i];
+        }
+        if (total <= 0.0) continue;  // WeightError::InsufficientNonZero -> select_best_action
+        const double u = uni(sp->rng) * total;
+        double acc = 0.0;
+        int pick = nc - 1;
+        for (int i = 0; i < nc; i++) {
+            acc += weight[i];
+            if (acc > u) {
+                pick = i;
+                break;
+            }
+        }
+        out[g] = sp->c_moves[o + pick];
+    }
+    return TZ_OK;
+}
+
+// one symmetric Dir(alpha) sample per root, of dimension n_children (noise.rs:17-19), zero padded to `w`.
+// ~100 gamma variates for each of thousands of roots: drawn by a fixed number of worker threads, each with its own
+// generator seeded from the driver's stream (fixed count, so the result does not depend on the machine).
+void dirichlet_rows(tz_selfplay* sp, int w) {
+    constexpr int WORKERS = 8;
+    sp->noise.assign((size_t)sp->B * w, 0.0f);
+    uint64_t seeds[WORKERS];
+    for (auto& x : seeds) x = sp->rng();
+    auto work = [&](int t) {
+        std::mt19937_64 rng(seeds[t]);
+        std::gamma_distribution<double> gamma(NOISE_ALPHA, 1.0);
+        std::vector<double> gsamp(w);
+        const int lo = (int)((int64_t)sp->B * t / WORKERS), hi = (int)((int64_t)sp->B * (t + 1) / WORKERS);
+        for (int g = lo; g < hi; g++) {
+            const int nc = (int)sp->info[g].n_children;
+            if (nc == 0) continue;
+            double sum = 0.0;
+            for (int i = 0; i < nc; i++) {
+                gsamp[i] = gamma(rng);
+                sum += gsamp[i];
+            }
+            if (!(sum > 0.0)) {  // every gamma underflowed: all mass on one child (what a tiny alpha tends to)
+                gsamp[0] = 1.0;
+                sum = 1.0;
+            }
+            for (int i = 0; i < nc; i++) sp->noise[(size_t)g * w + i] = (float)(gsamp[i] / sum);
+        }
+    };
+    if (sp->B < 256) {
+        for (int t = 0; t < WORKERS; t++) work(t);
+        return;
+    }
+    std::thread threads[WORKERS];
+    for (int t = 0; t < WORKERS; t++) threads[t] = std::thread(work, t);
+    for (auto& th : threads) th.join();
+}
+
+int record(tz_selfplay* sp) {  // take_a_step up to the step itself (selfplay/src/main.rs:238-257)
+    int w = 0, rc;
+    if ((rc = fetch_children(sp, &w))) return rc;
+    sp->history.emplace_back();
+    MoveRecord& m = sp->history.back();
+    const int B = sp->B;
+    m.width = w;
+    m.states.resize(B);
+    if ((rc = tz_search_get_positions(sp->search, m.states.data()))) return rc;
+    m.moves = sp->c_moves;
+    m.pol.assign((size_t)B * w, 0.0f);
+    m.nchild.resize(B);
+    m.stepped.resize(B);
+    m.actions = sp->actions;
+    m.ube.resize(B);
+    if (sp->kind == 0) {  // policy_target_from_proportional_visits (target.rs:151-164)
+        for (int g = 0; g < B; g++) {
+            const float denom = (float)std::max<uint32_t>(sp->info[g].visit_count, 1u);
+            for (int i = 0; i < (int)sp->info[g].n_children; i++)
+                m.pol[(size_t)g * w + i] = (float)sp->c_visits[(size_t)g * w + i] / denom;
+        }
+    } else if (sp->kind == 2) {  // uniform policy of the pre-training games (learn/src/main.rs:451-454)
+        for (int g = 0; g < B; g++) {
+            const float p = 1.0f / (float)std::max<uint32_t>(sp->info[g].n_children, 1u);
+            for (int i = 0; i < (int)sp->info[g].n_children; i++) m.pol[(size_t)g * w + i] = p;
+        }
+    } else {  // improved_policy(IMPROVED_POLICY_VISITATIONS) (selfplay/src/main.rs:47-52, 246-250)
+        int lg = 0;
+        while ((1 << (lg + 1)) <= sp->k) lg++;
+        const float visitations = (float)((sp->sims / lg / sp->k) * ((1 << lg) - 1));
+        if ((rc = tz_search_improved_policy(sp->search, visitations, w, m.pol.data()))) return rc;
+    }
+    if (sp->kind == 2) {
+        for (int g = 0; g < B; g++) m.ube[g] = 4.0f - 1.1920929e-07f;  // MAXIMUM_VARIANCE - f32::EPSILON (learn/src/main.rs:460)
+    } else if ((rc = tz_search_ube_target(sp->search, BETA, m.ube.data()))) {
+        return rc;
+    }
+    for (int g = 0; g < B; g++) {
+        m.nchild[g] = sp->info[g].n_children;
+        // batched.rs:137: a root that is terminal is not stepped
+        m.stepped[g] = !(sp->info[g].eval_tag != TZ_EVAL_VALUE && sp->info[g].eval.ply == 0);
+    }
+    return TZ_OK;
+}
+
+int complete(tz_selfplay* sp) {  // restart_envs_and_complete_targets (selfplay/src/main.rs:263-329)
+    const int B = sp->B;
+    bool any = false;
+    for (int g = 0; g < B; g++) any = any || sp->term[g] != TZ_TERMINAL_NONE;
+    sp->t_states.clear();
+    sp->t_moves.clear();
+    sp->t_pol.clear();
+    sp->t_value.clear();
+    sp->t_ube.clear();
+    sp->t_n.clear();
+    if (any) {
+        int rc;
+        std::vector<tz_state> fresh(B);
+        if ((rc = tz_search_get_positions(sp->search, fresh.data()))) return rc;
+        if ((rc = tz_search_terminal_details(sp->search, sp->reason.data(), sp->winner.data()))) return rc;
+        const int amax = sp->amax;
+        char buf[256];
+        std::vector<uint16_t> acts;
+        for (int g = 0; g < B; g++) {
+            if (sp->term[g] == TZ_TERMINAL_NONE) continue;
+            uint8_t tag = sp->term[g] == TZ_TERMINAL_WIN ? TZ_EVAL_WIN : sp->term[g] == TZ_TERMINAL_LOSS ? TZ_EVAL_LOSS : TZ_EVAL_DRAW;
+            uint32_t ply = 0;
+            acts.clear();
+            const int64_t first = sp->game_start[g] - sp->history_base;
+            for (int64_t h = (int64_t)sp->history.size() - 1; h >= first; h--) {
+                const MoveRecord& m = sp->history[(size_t)h];
+                if (!m.stepped[g]) continue;
+                tag = tag == TZ_EVAL_WIN ? TZ_EVAL_LOSS : tag == TZ_EVAL_LOSS ? TZ_EVAL_WIN : TZ_EVAL_DRAW;  // value.negate()
+                ply++;
+                acts.push_back(m.actions[g]);
+                const tz_state& st = m.states[g];
+                // "Only generate targets from non-exploratory episodes (or after the initial exploration)"
+                if (sp->betas[g] == 0.0f || st.ply > WEIGHTED_RANDOM_PLIES) {
+                    const int kk = (int)m.nchild[g];
+                    sp->t_states.push_back(st);
+                    const size_t off = sp->t_moves.size();
+                    sp->t_moves.resize(off + amax, 0);
+                    sp->t_pol.resize(off + amax, 0.0f);
+                    memcpy(&sp->t_moves[off], &m.moves[(size_t)g * m.width], sizeof(uint16_t) * kk);
+                    memcpy(&sp->t_pol[off], &m.pol[(size_t)g * m.width], sizeof(float) * kk);
+                    sp->t_n.push_back(kk);
+                    sp->t_value.push_back(eval_to_f32(tag, ply));
+                    sp->t_ube.push_back(m.ube[g]);
+                }
+            }
+            // Replay: start position, the moves in playing order, PTN result (target.rs:215-232)
+            std::string line = "[TPS \"";
+            if ((rc = tz_state_to_tps(&sp->start_states[g], buf, sizeof buf))) return rc;
+            line += buf;
+            line += "\"]";
+            std::string expl = line;
+            int count = 0;
+            for (auto it = acts.rbegin(); it != acts.rend(); ++it, ++count) {
+                if ((rc = tz_move_to_ptn(sp->n, *it, buf, sizeof buf))) return rc;
+                line += ' ';
+                line += buf;
+                if (count < WEIGHTED_RANDOM_PLIES) {
+                    expl += ' ';
+                    expl += buf;
+                }
+            }
+            line += ' ';
+            line += result_string(sp->reason[g], sp->winner[g]);
+            line += '\n';
+            sp->replays_text += line;
+            sp->n_replays++;
+            if (sp->betas[g] > 0.0f) {  // feature "exploration": the opening of an exploratory game (:279-290)
+                expl += '\n';
+                sp->exploration_text += expl;
+            }
+            sp->game_start[g] = sp->moves_played + 1;
+            sp->start_states[g] = fresh[g];
+        }
+        const int T = (int)sp->t_n.size();
+        if (T > 0) {
+            uint64_t total_moves = 0;
+            for (int v : sp->t_n) total_moves += (uint64_t)v;
+            std::vector<char> out((size_t)T * 200 + total_moves * 40);
+            uint64_t written = 0;
+            if ((rc = tz_format_targets(sp->n, T, sp->t_states.data(), sp->t_moves.data(), sp->t_pol.data(), sp->t_n.data(), amax,
+                                        sp->t_value.data(), sp->t_ube.data(), out.data(), out.size(), &written)))
+                return rc;
+            sp->targets_text.append(out.data(), written);
+            sp->n_targets += (uint64_t)T;
+        }
+    }
+    // drop the records no running game refers to any more
+    int64_t oldest = sp->moves_played + 1;
+    for (int g = 0; g < B; g++) oldest = std::min(oldest, sp->game_start[g]);
+    while (sp->history_base < oldest && !sp->history.empty()) {
+        sp->history.pop_front();
+        sp->history_base++;
+    }
+    return TZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// search_kind: 0 = PUCT + Dirichlet (the north star's loop, selfplay/src/main.rs:127-136), 1 = Gumbel sequential
+// halving with `sampled_actions` (:138-153), 2 = uniformly random legal moves (learn's pre-training games).
+// exploration != 0: the first half of the games search with beta = 0.25 (cargo feature "exploration", :79-86).
+int tz_selfplay_create(tz_search* search, int sims_per_move, uint64_t seed, int shard, int search_kind, int sampled_actions,
+                       int exploration, tz_selfplay** out) {
+    if (!search || !out || search_kind < 0 || search_kind > 2 || sims_per_move < 0)
+        return tz_fail(TZ_EINVAL, "tz_selfplay_create: bad argument");
+    *out = nullptr;
+    std::unique_ptr<tz_selfplay> sp(new tz_selfplay());
+    sp->search = search;
+    int rc = tz_search_shape(search, &sp->B, &sp->n, &sp->half_komi, &sp->amax);
+    if (rc) return rc;
+    sp->sims = sims_per_move;
+    sp->kind = search_kind;
+    sp->k = sampled_actions > 0 ? sampled_actions : 64;
+    if (search_kind == 1 && (sp->k & (sp->k - 1))) return tz_fail(TZ_EINVAL, "tz_selfplay_create: sampled_actions must be a power of two");
+    const int B = sp->B;
+    sp->betas.assign(B, 0.0f);
+    if (exploration)
+        for (int g = 0; g < B / 2; g++) sp->betas[g] = BETA;
+    std::seed_seq seq{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)shard, 0x7a6b5c4du};
+    sp->rng.seed(seq);
+    sp->game_start.assign(B, 0);
+    sp->start_states.resize(B);
+    sp->info.resize(B);
+    sp->actions.resize(B);
+    sp->best.resize(B);
+    sp->choice.resize(B);
+    sp->term.resize(B);
+    sp->reason.resize(B);
+    sp->winner.resize(B);
+    std::uniform_int_distribution<int> open(0, 15);
+    for (int g = 0; g < B; g++) sp->choice[g] = open(sp->rng);
+    if ((rc = tz_search_new_openings(search, sp->choice.data()))) return rc;
+    if ((rc = tz_search_get_positions(search, sp->start_states.data()))) return rc;
+    *out = sp.release();
+    return TZ_OK;
+}
+
+int tz_selfplay_destroy(tz_selfplay* sp) {
+    delete sp;
+    return TZ_OK;
+}
+
+// One outer-loop iteration of selfplay::main: search, pick the moves, record the targets-to-be, step, restart the
+// finished games and complete their targets / replays (kept as text until taken).
+int tz_selfplay_play_move(tz_selfplay* sp) {
+    if (!sp) return tz_fail(TZ_EINVAL, "tz_selfplay_play_move: null handle");
+    const int B = sp->B;
+    int rc, w = 0;
+    if (sp->kind == 0) {
+        if ((rc = tz_search_simulate(sp->search, sp->betas.data(), 1))) return rc;            // :128
+        if ((rc = tz_search_root_info(sp->search, sp->info.data()))) return rc;
+        w = 1;
+        for (int g = 0; g < B; g++) w = std::max(w, (int)sp->info[g].n_children);
+        dirichlet_rows(sp, w);
+        if ((rc = tz_search_apply_noise(sp->search, sp->noise.data(), w, NOISE_RATIO))) return rc;  // :131
+        if ((rc = tz_search_simulate(sp->search, sp->betas.data(), sp->sims))) return rc;        // :134-136
+        if ((rc = select_actions_in_selfplay(sp, sp->actions))) return rc;                        // batched.rs:165-183
+    } else if (sp->kind == 2) {
+        if ((rc = tz_search_simulate(sp->search, sp->betas.data(), 1))) return rc;
+        if ((rc = fetch_children(sp, &w))) return rc;
+        std::uniform_real_distribution<double> uni(0.0, 1.0);
+        for (int g = 0; g < B; g++) {
+            const int nc = (int)sp->info[g].n_children;
+            const int j = nc > 0 ? std::min(nc - 1, (int)(uni(sp->rng) * nc)) : 0;
+            sp->actions[g] = nc > 0 ? sp->c_moves[(size_t)g * w + j] : (uint16_t)0xFFFF;
+        }
+    } else {
+        sp->gumbel.resize((size_t)B * sp->amax);
+        std::uniform_real_distribution<double> uni(0.0, 1.0);
+        for (auto& x : sp->gumbel) {
+            double u = uni(sp->rng);
+            if (u <= 0.0) u = 1e-300;
+            x = (float)(-std::log(-std::log(u)));  // Gumbel(0, 1)
+        }
+        if ((rc = tz_search_gumbel_sh(sp->search, sp->betas.data(), sp->k, sp->sims, sp->gumbel.data(), sp->amax, sp->actions.data())))
+            return rc;                                                                           // :138-144
+        if ((rc = tz_search_root_info(sp->search, sp->info.data()))) return rc;
+        bool early = false;
+        for (int g = 0; g < B; g++) early = early || sp->info[g].ply < WEIGHTED_RANDOM_PLIES;
+        if (early) {                                                                             // :145-153
+            std::vector<uint16_t> sampled;
+            std::vector<uint16_t> ply(B);
+            for (int g = 0; g < B; g++) ply[g] = sp->info[g].ply;
+            if ((rc = select_actions_in_selfplay(sp, sampled))) return rc;
+            for (int g = 0; g < B; g++)
+                if (ply[g] < WEIGHTED_RANDOM_PLIES) sp->actions[g] = sampled[g];
+        }
+    }
+    if ((rc = record(sp))) return rc;
+    if ((rc = tz_search_step(sp->search, sp->actions.data()))) return rc;                        // take_a_step
+    std::uniform_int_distribution<int> open(0, 15);
+    for (int g = 0; g < B; g++) sp->choice[g] = open(sp->rng);
+    if ((rc = tz_search_restart_terminal(sp->search, sp->choice.data(), sp->term.data()))) return rc;
+    if ((rc = complete(sp))) return rc;
+    sp->moves_played++;
+    sp->positions += (uint64_t)B;
+    return TZ_OK;
+}
+
+// counters since creation: moves played, targets and replays completed
+int tz_selfplay_counters(tz_selfplay* sp, uint64_t* moves_out, uint64_t* targets_out, uint64_t* replays_out) {
+    if (!sp) return tz_fail(TZ_EINVAL, "tz_selfplay_counters: null handle");
+    if (moves_out) *moves_out = (uint64_t)sp->moves_played;
+    if (targets_out) *targets_out = sp->n_targets;
+    if (replays_out) *replays_out = sp->n_replays;
+    return TZ_OK;
+}
+
+// Moves the text accumulated since the last call out of the driver: which = 0 target lines, 1 replay lines,
+// 2 exploration replay lines.  *size_out = bytes available; copied (and cleared) only if cap is large enough.
+int tz_selfplay_take_text(tz_selfplay* sp, int which, char* out, uint64_t cap, uint64_t* size_out) {
+    if (!sp || which < 0 || which > 2 || !size_out) return tz_fail(TZ_EINVAL, "tz_selfplay_take_text: bad argument");
+    std::string& s = which == 0 ? sp->targets_text : which == 1 ? sp->replays_text : sp->exploration_text;
+    *size_out = s.size();
+    if (!out || cap < s.size()) return s.empty() ? TZ_OK : TZ_ECAPACITY;
+    memcpy(out, s.data(), s.size());
+    s.clear();
+    return TZ_OK;
+}
+
+// selfplay::main on a directory (selfplay/src/main.rs:88-205) for `moves` iterations (< 0: forever): wait while
+// buffer_lengths.txt says learn has more than `max_buffer_len` self-play targets (:90-105, 371-387), call `reload`
+// (Net::load of model_latest, :107-121; may be null), play a move, append targets-selfplay<suffix>.txt /
+// replays<suffix>.txt / replays-exploration<suffix>.txt from a writer thread.  wait_limit_s < 0: wait forever.
+int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_buffer_len, const char* suffix,
+                    int (*reload)(void*), void* reload_user, double wait_limit_s) {
+    if (!sp || !directory) return tz_fail(TZ_EINVAL, "tz_selfplay_run: bad argument");
+    const std::string dir = directory, suf = suffix ? suffix : "";
+    struct Job {
+        std::string targets, replays, expl;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> queue;
+    bool done = false;
+    std::string write_error;
+    auto append = [&](const std::string& name, const std::string& text) {
+        if (text.empty()) return;
+        FILE* f = fopen((dir + "/" + name + suf + ".txt").c_str(), "ab");  // OpenOptions::append(true).create(true)
+        if (!f || fwrite(text.data(), 1, text.size(), f) != text.size()) write_error = "cannot append to " + name;
+        if (f) fclose(f);
+    };
+    std::thread writer([&] {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return done || !queue.empty(); });
+                if (queue.empty()) return;
+                job = std::move(queue.front());
+                queue.pop_front();
+            }
+            append("targets-selfplay", job.targets);
+            append("replays", job.replays);
+            append("replays-exploration", job.expl);
+        }
+    });
+    auto finish = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+        }
+        cv.notify_all();
+        writer.join();
+    };
+    int rc = TZ_OK;
+    for (int step = 0; moves < 0 || step < moves; step++) {
+        double waited = 0.0;
+        for (;;) {  // the inner `loop` of selfplay::main
+            long a = -1, b = -1, c = -1;
+            FILE* f = fopen((dir + "/buffer_lengths.txt").c_str(), "rb");
+            const bool ok = f && fscanf(f, "%ld,%ld,%ld", &a, &b, &c) == 3 && a + b == c;
+            if (f) fclose(f);
+            if (ok && a <= max_buffer_len) break;
+            if (wait_limit_s >= 0 && waited >= wait_limit_s) {
+                finish();
+                return tz_fail(TZ_ESTATE, ok ? "tz_selfplay_run: learn's buffer stayed over its cap" : "tz_selfplay_run: buffer_lengths.txt unreadable");
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(wait_limit_s >= 0 && wait_limit_s < 1 ? 10 : 1000));
+            waited += wait_limit_s >= 0 && wait_limit_s < 1 ? 0.01 : 1.0;
+        }
+        if (reload && (rc = reload(reload_user))) break;
+        if ((rc = tz_selfplay_play_move(sp))) break;
+        Job job;
+        job.targets.swap(sp->targets_text);
+        job.replays.swap(sp->replays_text);
+        job.expl.swap(sp->exploration_text);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(std::move(job));
+        }
+        cv.notify_one();
+    }
+    finish();
+    if (!rc && !write_error.empty()) return tz_fail(TZ_ESTATE, "tz_selfplay_run: " + write_error);
+    return rc;
+}
+
+}  // extern "C"

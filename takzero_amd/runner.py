@@ -23,6 +23,12 @@ MAX_REANALYZE_BUFFER_LEN = 32_000  # reanalyze/src/main.rs:40
 MIN_POSITIONS = 4000 * 128 // 4    # reanalyze/src/main.rs:38
 
 
+def _lib_error():
+    from ._lib import TakzeroError
+
+    return TakzeroError
+
+
 def read_buffer_lengths(directory):
     with open(os.path.join(directory, "buffer_lengths.txt")) as f:
         return formats.parse_buffer_lengths(f.read())
@@ -197,12 +203,53 @@ def append_lines(path, lines):
 
 def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, world=1, search="gumbel",
                  sampled_actions=64, gather=False, watch_model=True, exploration=False, broadcast_model=False,
-                 sleep=1.0, max_wait=None, log=None):
+                 native=False, sleep=1.0, max_wait=None, log=None):
     """selfplay::main (selfplay/src/main.rs:63-205) for `moves` outer iterations (None = forever).
     exploration = the cargo feature of that name: the first half of the games search with beta = 0.25 and the
     openings of those games also go to replays-exploration.txt (:79-86, 279-290).
-    broadcast_model: only rank 0 reads model_latest.ot, the other ranks receive the tensors over torch.distributed."""
+    broadcast_model: only rank 0 reads model_latest.ot, the other ranks receive the tensors over torch.distributed.
+    native: run the loop in native code (tz_selfplay_run, csrc/tz_host.cpp) instead of this Python mirror of it."""
     n = mcts.n
+    if native:
+        # the whole loop below the ABI (csrc/tz_host.cpp): search, bookkeeping, formatting, file appends, back-pressure
+        from .selfplay import NativeSelfPlay
+
+        if gather:
+            raise ValueError("native run writes per-rank files; gather the files' consumers instead")
+        sp = NativeSelfPlay(mcts, sims_per_move, seed=seed, shard=rank, search=search, sampled_actions=sampled_actions,
+                            exploration=exploration)
+        watcher = None
+        if watch_model:
+            watcher = BroadcastModelWatcher(mcts.agent, directory, rank) if broadcast_model and world > 1 else \
+                ModelWatcher(mcts.agent, directory)
+
+        def reload():
+            if watcher is None:
+                return
+            t0 = time.monotonic()
+            while True:   # missing file: retry (selfplay/src/main.rs:116-119); unreadable archive: keep the old net (:112-115)
+                try:
+                    watcher.refresh()
+                    return
+                except OSError as err:
+                    if log:
+                        log("Cannot load model: %s, retrying." % err)
+                    if max_wait is not None and time.monotonic() - t0 > max_wait:
+                        raise TimeoutError("no model for %.0f s" % max_wait)
+                    time.sleep(sleep)
+                except Exception as err:
+                    if log:
+                        log("Cannot load model (parse error): %s" % err)
+                    return
+
+        try:
+            sp.run(directory, moves=moves, max_buffer_len=MAX_SELFPLAY_BUFFER_LEN, suffix="" if world == 1 else "-rank%d" % rank,
+                   reload=reload if watcher is not None else None, wait_limit_s=-1.0 if max_wait is None else float(max_wait))
+        except _lib_error() as e:
+            if e.code == -6:   # TZ_ESTATE: buffer_lengths.txt stayed unreadable / over the cap for max_wait
+                raise TimeoutError(str(e))
+            raise
+        return sp
     betas = None
     if exploration:
         from .selfplay import BETA

@@ -227,3 +227,108 @@ def all_gather_targets(targets, n, device=None):
         if counts[r]:
             out.extend(unpack_targets(gathered[r][:counts[r]].cpu().numpy(), n))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+class NativeSelfPlay:
+    """The same driver in native code (csrc/tz_host.cpp, tz_selfplay_*): the whole outer loop of selfplay::main —
+    search, move choice, target bookkeeping, line formatting — runs below the ABI; this class only forwards.
+    Finished targets / replays come back as text lines (take_lines) or go straight to files (run)."""
+
+    KINDS = {"puct": 0, "gumbel": 1, "random": 2}
+
+    def __init__(self, mcts, sims_per_move, seed=0, shard=0, search="puct", sampled_actions=64, exploration=False):
+        import ctypes as C
+
+        from . import _lib
+
+        self.mcts, self.lib = mcts, _lib.load()
+        self.h = C.c_void_p()
+        _lib.check(self.lib.tz_selfplay_create(mcts.h, sims_per_move, seed, shard, self.KINDS[search], sampled_actions,
+                                               1 if exploration else 0, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tz_selfplay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def play_move(self):
+        from . import _lib
+
+        _lib.check(self.lib.tz_selfplay_play_move(self.h))
+
+    def counters(self):
+        import ctypes as C
+
+        from . import _lib
+
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.tz_selfplay_counters(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"moves": a.value, "targets": b.value, "replays": c.value}
+
+    def take_text(self, which=0):
+        """bytes of the target (0) / replay (1) / exploration replay (2) lines finished since the last call."""
+        import ctypes as C
+
+        from . import _lib
+
+        size = C.c_uint64()
+        rc = self.lib.tz_selfplay_take_text(self.h, which, None, 0, C.byref(size))
+        if size.value == 0:
+            return b""
+        buf = C.create_string_buffer(size.value)
+        _lib.check(self.lib.tz_selfplay_take_text(self.h, which, buf, size.value, C.byref(size)))
+        return buf.raw[:size.value]
+
+    def run(self, directory, moves=None, max_buffer_len=32_000, suffix="", reload=None, wait_limit_s=-1.0):
+        """tz_selfplay_run: the directory loop.  `reload` (optional) is called before every move and may swap weights."""
+        import ctypes as C
+
+        from . import _lib
+
+        cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p)
+        failure = []
+
+        def trampoline(_user):
+            try:
+                reload()
+                return 0
+            except Exception as e:   # surfaces after the native loop returns
+                failure.append(e)
+                return -6
+
+        cb = cb_type(trampoline) if reload is not None else None
+        rc = self.lib.tz_selfplay_run(self.h, str(directory).encode(), -1 if moves is None else moves, max_buffer_len,
+                                      suffix.encode(), C.cast(cb, C.c_void_p) if cb is not None else None, None, wait_limit_s)
+        if failure:
+            raise failure[0]
+        _lib.check(rc)
+
+
+def all_gather_bytes(data, device=None):
+    """Every rank contributes a byte string (its finished target lines); every rank receives the concatenation in rank
+    order.  Sizes first, then zero-padded payloads (NCCL = RCCL on the GPU box, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return data
+    world = dist.get_world_size()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    size = torch.tensor([len(data)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    width = max(max(sizes), 1)
+    mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+    if data:
+        mine[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    parts = [torch.zeros(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return b"".join(bytes(p[:s].cpu().numpy().tobytes()) for p, s in zip(parts, sizes))

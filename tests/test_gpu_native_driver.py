@@ -1,0 +1,109 @@
+"""The native self-play driver (csrc/tz_host.cpp, tz_selfplay_*): the outer loop of selfplay::main below the ABI.
+Its output is held to what the reference's own consumers require: every target line parses and lists exactly the legal
+moves of its position, values are discounted game results, every replay re-validates move by move through the oracle
+and ends in the terminal result it names; same seed -> same bytes."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_util import require_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(A, n=4, B=48, seed=7):
+    from takzero_amd import weights as W
+
+    net = A.Net(arch=A.ARCH_TEST, n=n, precision=A.PREC_BF16, blocks=1).load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=seed))
+    return net, A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 13)
+
+
+def _check_lines(oracle, n, targets, replays, search):
+    from takzero_amd import formats as F
+
+    assert targets and replays
+    for line in targets.decode().splitlines(keepends=True):
+        st, mv, pol, value, ube = F.parse_target(line, n, 4)
+        legal = O.possible_moves(oracle, O.TzState.from_buffer_copy(np.array([st]).tobytes()))
+        assert [int(m) for m in mv] == list(legal)          # exactly the legal moves, in possible_moves order
+        total = float(pol.sum(dtype=np.float64))
+        assert abs(total - 1.0) < (0.15 if search == "puct" else 1e-3)
+        assert 0.0 <= ube <= 4.0
+        if value != 0.0:                                    # +-0.997^k, k >= 1 plies before the end
+            k = math.log(abs(float(value))) / math.log(0.997)
+            assert k > 0.5 and abs(k - round(k)) < 1e-2, value
+        assert F.format_target(n, st, mv, pol, value, ube) == line
+    moves_total = 0
+    for line in replays.decode().splitlines():
+        start, moves = F.parse_replay(line, n, 4)
+        s = O.TzState.from_buffer_copy(np.array([start]).tobytes())
+        for m in moves:
+            assert oracle.tzo_terminal(C.byref(s)) == -1
+            s = O.play(oracle, s, int(m))
+        assert oracle.tzo_terminal(C.byref(s)) != -1
+        tag = line.split()[-1]
+        assert tag in {1: ("R-0", "F-0"), 2: ("0-R", "0-F"), 3: ("1/2-1/2",)}[oracle.tzo_result(C.byref(s))]
+        moves_total += len(moves)
+    return moves_total
+
+
+@pytest.mark.parametrize("search,sims,k", [("puct", 12, 64), ("gumbel", 16, 4), ("random", 0, 64)])
+def test_native_driver_output_is_what_learn_and_reanalyze_accept(oracle, search, sims, k):
+    A = require_gpu()
+    from takzero_amd import selfplay as SP
+
+    n = 4
+    outs = []
+    for run in range(2):
+        net, mcts = _setup(A, n)
+        if search == "random":
+            mcts = A.BatchedMCTS(48, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 10)
+        sp = SP.NativeSelfPlay(mcts, sims, seed=3, shard=0, search=search, sampled_actions=k)
+        for _ in range(70):
+            sp.play_move()
+        outs.append((sp.take_text(0), sp.take_text(1), sp.counters()))
+        assert sp.take_text(0) == b"" and sp.take_text(1) == b""   # taken means gone
+    assert outs[0][:2] == outs[1][:2], "same seed, same shard: same bytes"
+    targets, replays, counters = outs[0]
+    assert counters["moves"] == 70 and counters["replays"] == replays.count(b"\n") and counters["targets"] == targets.count(b"\n")
+    moves_total = _check_lines(oracle, n, targets, replays, search)
+    assert counters["targets"] == moves_total   # beta = 0: every position of every finished game is a target
+    net, mcts = _setup(A, n)
+    other = SP.NativeSelfPlay(mcts if search != "random" else A.BatchedMCTS(48, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 10),
+                              sims, seed=3, shard=1, search=search, sampled_actions=k)
+    for _ in range(70):
+        other.play_move()
+    assert other.take_text(1) != replays, "another shard draws another stream"
+
+
+def test_native_directory_loop_with_exploration_and_back_pressure(oracle, tmp_path):
+    A = require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import runner as R
+
+    d, n = str(tmp_path), 4
+    net, mcts = _setup(A, n, B=32)
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(10, 20))
+    sp = R.run_selfplay(d, mcts, 16, moves=60, seed=5, search="gumbel", sampled_actions=4, watch_model=False, exploration=True,
+                        native=True, max_wait=5)
+    assert sp.counters()["moves"] == 60
+    targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
+    replays = open(os.path.join(d, "replays.txt"), "rb").read()
+    expl = open(os.path.join(d, "replays-exploration.txt")).read().splitlines()
+    moves_total = _check_lines(oracle, n, targets, replays, "gumbel")
+    assert 0 < len(expl) < replays.count(b"\n")
+    full = {tuple(line.split()[:2 + 10 + 3]) for line in replays.decode().splitlines()}
+    for line in expl:
+        toks = line.split()
+        assert len(toks) <= 5 + 10      # '[TPS', three TPS fields ... plus at most ten moves, no result
+    assert targets.count(b"\n") < moves_total   # exploratory games only give targets after ply 10
+    # learn says its self-play buffer is full: nothing is played
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(R.MAX_SELFPLAY_BUFFER_LEN + 1, 0))
+    before = os.path.getsize(os.path.join(d, "replays.txt"))
+    with pytest.raises(TimeoutError):
+        R.run_selfplay(d, mcts, 16, moves=1, watch_model=False, native=True, max_wait=0.1)
+    assert os.path.getsize(os.path.join(d, "replays.txt")) == before
