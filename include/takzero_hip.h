@@ -245,6 +245,22 @@ int tz_selfplay_take_text(tz_selfplay* sp, int which, char* out, uint64_t cap, u
 int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_buffer_len, const char* suffix,
                     int (*reload)(void*), void* reload_user, double wait_limit_s);
 
+/* ---------- reanalyze::main above the search (reanalyze/src/main.rs:60-290), native host code ----------
+ * Position buffer fed from replays.txt (complete lines appended since the last call; line i belongs to rank i % world;
+ * every pre-move state of a replay, moves re-validated on the device), B positions sampled without replacement,
+ * fresh trees, search (0 = `sims` PUCT simulations, 1 = Gumbel sequential halving with budget `sims`), one target per
+ * position: value = root evaluation if solved else -evaluation(selected child), policy =
+ * improved_policy(most_visited_count()), ube = ube_target(0.25). */
+typedef struct tz_reanalyze tz_reanalyze;
+int tz_reanalyze_create(tz_search* search, int sims, uint64_t seed, int rank, int world, int search_kind, int sampled_actions,
+                        tz_reanalyze** out);
+int tz_reanalyze_destroy(tz_reanalyze* ra);
+int tz_reanalyze_feed(tz_reanalyze* ra, const char* replays_path, uint64_t* added_out, uint64_t* total_out);
+int tz_reanalyze_iterate(tz_reanalyze* ra);
+int tz_reanalyze_take_text(tz_reanalyze* ra, char* out, uint64_t cap, uint64_t* size_out);
+int tz_reanalyze_run(tz_reanalyze* ra, const char* directory, int iterations, int min_positions, const char* suffix,
+                     int (*reload)(void*), void* reload_user, double wait_limit_s);
+
 /* ---------- Target lines in bulk (impl Display / FromStr for Target, target.rs:56-73, 99-143) ----------
  * "{tps};{value};{ube};{move}:{p},...\n" with Rust's `Display for f32`.  moves / policy are [count][amax]. */
 int tz_format_targets(int n, int count, const tz_state* states, const uint16_t* moves, const float* policy,

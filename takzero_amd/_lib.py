@@ -34,7 +34,8 @@ SYMBOLS = [
     "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
     "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
     "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
-    "tz_selfplay_run",
+    "tz_selfplay_run", "tz_reanalyze_create", "tz_reanalyze_destroy", "tz_reanalyze_feed", "tz_reanalyze_iterate",
+    "tz_reanalyze_take_text", "tz_reanalyze_run",
 ]
 
 _lib = None
@@ -112,6 +113,12 @@ def load():
     lib.tz_selfplay_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 3
     lib.tz_selfplay_take_text.argtypes = [vp, ci, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.tz_selfplay_run.argtypes = [vp, C.c_char_p, ci, ci, C.c_char_p, vp, vp, C.c_double]
+    lib.tz_reanalyze_create.argtypes = [vp, ci, C.c_uint64, ci, ci, ci, ci, C.POINTER(vp)]
+    lib.tz_reanalyze_destroy.argtypes = [vp]
+    lib.tz_reanalyze_feed.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.tz_reanalyze_iterate.argtypes = [vp]
+    lib.tz_reanalyze_take_text.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.tz_reanalyze_run.argtypes = [vp, C.c_char_p, ci, ci, C.c_char_p, vp, vp, C.c_double]
     lib.tz_trainer_create.argtypes = [ci, ci, ci, ci, ci, cf, C.POINTER(vp)]
     lib.tz_trainer_destroy.argtypes = [vp]
     lib.tz_trainer_tensor_count.argtypes = [vp]

@@ -544,3 +544,321 @@ int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_b
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// reanalyze::main above the search (reanalyze/src/main.rs:60-290): the position buffer fed from replays.txt
+// (fill_buffer_with_positions_from_replays, :270-290; Replay::from_str / Replay::states, target.rs:205-268), sampling
+// without replacement (:154-158), fresh trees on overwritten envs (:159-165), search, and the target of every position
+// (:179-228) as text lines.
+namespace {
+constexpr int MIN_POSITIONS = 4000 * 128 / 4;  // reanalyze/src/main.rs:38
+constexpr int MAX_REANALYZE_BUFFER_LEN = 32000;  // :40
+}  // namespace
+
+struct tz_reanalyze {
+    tz_search* search = nullptr;
+    int B = 0, n = 0, half_komi = 0, amax = 0;
+    int sims = 0, kind = 0, k = 64, rank = 0, world = 1;
+    std::mt19937_64 rng;
+    std::vector<tz_state> positions;
+    uint64_t offset = 0, line_no = 0;
+    std::string targets_text;
+    uint64_t n_targets = 0;
+};
+
+namespace {
+
+struct ParsedReplay {
+    tz_state start;
+    std::vector<uint16_t> moves;
+};
+
+bool parse_replay_line(const char* b, const char* e, int n, int half_komi, ParsedReplay& out) {
+    static const char prefix[] = "[TPS \"";
+    if (e - b < 8 || memcmp(b, prefix, 6) != 0) return false;
+    const char* q = b + 6;
+    const char* close = nullptr;
+    for (const char* p = q; p + 1 < e; p++)
+        if (p[0] == '"' && p[1] == ']') {
+            close = p;
+            break;
+        }
+    if (!close) return false;
+    const std::string tps(q, close);
+    if (tz_state_from_tps(tps.c_str(), n, half_komi, &out.start)) return false;
+    out.moves.clear();
+    const char* p = close + 2;
+    while (p < e) {
+        while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+        const char* t = p;
+        while (p < e && *p != ' ' && *p != '\t' && *p != '\r') p++;
+        if (p == t) break;
+        const std::string tok(t, p);
+        if (tok == "R-0" || tok == "0-R" || tok == "F-0" || tok == "0-F" || tok == "1/2-1/2" || tok == "1-0" || tok == "0-1") break;
+        if (tok.back() == '.' && tok.find_first_not_of("0123456789") == tok.size() - 1) continue;  // move numbers
+        uint16_t mv;
+        if (tz_move_from_ptn(n, tok.c_str(), &mv)) return false;
+        out.moves.push_back(mv);
+    }
+    return true;
+}
+
+// every pre-move state of every replay, validated on the device; a replay with an illegal move is dropped whole
+// (the reference's line fails to parse, target.rs:248-268)
+int expand_replays(tz_reanalyze* ra, const std::vector<ParsedReplay>& replays, uint64_t* added_out) {
+    const int B = ra->B;
+    std::vector<int32_t> idx(B);
+    std::vector<tz_state> states(B), cur(B);
+    std::vector<uint16_t> acts(B);
+    std::vector<int8_t> ok(B);
+    uint64_t added = 0;
+    for (size_t base = 0; base < replays.size(); base += (size_t)B) {
+        const int cnt = (int)std::min<size_t>(B, replays.size() - base);
+        for (int g = 0; g < cnt; g++) {
+            idx[g] = g;
+            states[g] = replays[base + g].start;
+        }
+        int rc = tz_search_set_positions(ra->search, cnt, idx.data(), states.data());
+        if (rc) return rc;
+        std::vector<std::vector<tz_state>> per_game(cnt);
+        std::vector<char> alive(B, 0), dropped(cnt, 0);
+        for (int g = 0; g < cnt; g++) alive[g] = 1;
+        for (size_t ply = 0;; ply++) {
+            bool any = false;
+            for (int g = 0; g < B; g++) {
+                acts[g] = 0xFFFF;
+                if (g < cnt && alive[g] && ply < replays[base + g].moves.size()) {
+                    acts[g] = replays[base + g].moves[ply];
+                    any = true;
+                } else if (g < cnt) {
+                    alive[g] = 0;
+                }
+            }
+            if (!any) break;
+            if ((rc = tz_search_get_positions(ra->search, cur.data()))) return rc;
+            if ((rc = tz_search_play_moves(ra->search, acts.data(), ok.data()))) return rc;
+            for (int g = 0; g < cnt; g++) {
+                if (!alive[g]) continue;
+                if (ok[g] == 1) {
+                    per_game[g].push_back(cur[g]);
+                } else {
+                    if (ok[g] == 0) dropped[g] = 1;  // illegal move: the whole line is rejected
+                    alive[g] = 0;
+                }
+            }
+        }
+        for (int g = 0; g < cnt; g++) {
+            if (dropped[g]) continue;
+            ra->positions.insert(ra->positions.end(), per_game[g].begin(), per_game[g].end());
+            added += per_game[g].size();
+        }
+    }
+    if (added_out) *added_out = added;
+    return TZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// search_kind: 0 = `sims` PUCT simulations per position (SURVEY config 5), 1 = Gumbel sequential halving with budget
+// `sims` and `sampled_actions` (reanalyze/src/main.rs:171-177).  rank / world: replay line i belongs to rank i % world.
+int tz_reanalyze_create(tz_search* search, int sims, uint64_t seed, int rank, int world, int search_kind, int sampled_actions,
+                        tz_reanalyze** out) {
+    if (!search || !out || sims <= 0 || world <= 0 || rank < 0 || rank >= world || search_kind < 0 || search_kind > 1)
+        return tz_fail(TZ_EINVAL, "tz_reanalyze_create: bad argument");
+    *out = nullptr;
+    std::unique_ptr<tz_reanalyze> ra(new tz_reanalyze());
+    ra->search = search;
+    int rc = tz_search_shape(search, &ra->B, &ra->n, &ra->half_komi, &ra->amax);
+    if (rc) return rc;
+    ra->sims = sims;
+    ra->kind = search_kind;
+    ra->k = sampled_actions > 0 ? sampled_actions : 64;
+    ra->rank = rank;
+    ra->world = world;
+    std::seed_seq seq{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)rank, 0x2e7a11u};
+    ra->rng.seed(seq);
+    *out = ra.release();
+    return TZ_OK;
+}
+
+int tz_reanalyze_destroy(tz_reanalyze* ra) {
+    delete ra;
+    return TZ_OK;
+}
+
+// fill_buffer_with_positions_from_replays: reads what was appended to `path` since the last call (complete lines only).
+int tz_reanalyze_feed(tz_reanalyze* ra, const char* path, uint64_t* added_out, uint64_t* total_out) {
+    if (!ra || !path) return tz_fail(TZ_EINVAL, "tz_reanalyze_feed: bad argument");
+    if (added_out) *added_out = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return tz_fail(TZ_EPARSE, std::string("tz_reanalyze_feed: cannot open ") + path);
+    std::string data;
+    if (fseek(f, (long)ra->offset, SEEK_SET) == 0) {
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+    }
+    fclose(f);
+    const size_t last_nl = data.rfind('\n');
+    std::vector<ParsedReplay> replays;
+    if (last_nl != std::string::npos) {
+        ra->offset += last_nl + 1;
+        size_t pos = 0;
+        while (pos <= last_nl) {
+            const size_t nl = data.find('\n', pos);
+            const bool mine = (int)(ra->line_no % (uint64_t)ra->world) == ra->rank;
+            ra->line_no++;
+            if (mine && nl > pos) {
+                ParsedReplay r;
+                if (parse_replay_line(data.data() + pos, data.data() + nl, ra->n, ra->half_komi, r)) replays.push_back(std::move(r));
+            }
+            pos = nl + 1;
+        }
+    }
+    int rc = expand_replays(ra, replays, added_out);
+    if (total_out) *total_out = ra->positions.size();
+    return rc;
+}
+
+// One outer-loop iteration (reanalyze/src/main.rs:146-228): B positions sampled without replacement, fresh trees,
+// search, one target line per position.  TZ_ESTATE if the buffer holds fewer than B positions.
+int tz_reanalyze_iterate(tz_reanalyze* ra) {
+    if (!ra) return tz_fail(TZ_EINVAL, "tz_reanalyze_iterate: null handle");
+    const int B = ra->B;
+    const size_t P = ra->positions.size();
+    if (P < (size_t)B) return tz_fail(TZ_ESTATE, "tz_reanalyze_iterate: fewer positions than the batch size");
+    // position_buffer.sample(rng, B): partial Fisher-Yates over the buffer itself (the order of the buffer is immaterial)
+    std::vector<tz_state> states(B);
+    for (int i = 0; i < B; i++) {
+        std::uniform_int_distribution<size_t> pick(i, P - 1);
+        std::swap(ra->positions[i], ra->positions[pick(ra->rng)]);
+        states[i] = ra->positions[i];
+    }
+    std::vector<int32_t> idx(B);
+    for (int g = 0; g < B; g++) idx[g] = g;
+    int rc = tz_search_set_positions(ra->search, B, idx.data(), states.data());
+    if (rc) return rc;
+    std::vector<float> zero_beta(B, 0.0f);
+    std::vector<uint16_t> selected(B);
+    if (ra->kind == 0) {
+        if ((rc = tz_search_simulate(ra->search, zero_beta.data(), ra->sims))) return rc;
+        if ((rc = tz_search_select_best_actions(ra->search, selected.data()))) return rc;
+    } else {
+        std::vector<float> gumbel((size_t)B * ra->amax);
+        std::uniform_real_distribution<double> uni(0.0, 1.0);
+        for (auto& x : gumbel) {
+            double u = uni(ra->rng);
+            if (u <= 0.0) u = 1e-300;
+            x = (float)(-std::log(-std::log(u)));
+        }
+        if ((rc = tz_search_gumbel_sh(ra->search, zero_beta.data(), ra->k, ra->sims, gumbel.data(), ra->amax, selected.data()))) return rc;
+    }
+    std::vector<tz_root_info> info(B);
+    if ((rc = tz_search_root_info(ra->search, info.data()))) return rc;
+    int w = 1;
+    for (int g = 0; g < B; g++) w = std::max(w, (int)info[g].n_children);
+    const size_t cells = (size_t)B * w;
+    std::vector<uint16_t> moves(cells);
+    std::vector<uint32_t> visits(cells), bits(cells);
+    std::vector<uint8_t> tag(cells);
+    if ((rc = tz_search_root_children(ra->search, w, moves.data(), visits.data(), tag.data(), bits.data(), nullptr, nullptr, nullptr)))
+        return rc;
+    std::vector<float> mvc(B), pol(cells), ube(B), value(B);
+    for (int g = 0; g < B; g++) {  // most_visited_count (node/mod.rs:209-213)
+        uint32_t m = 0;
+        for (int i = 0; i < (int)info[g].n_children; i++) m = std::max(m, visits[(size_t)g * w + i]);
+        mvc[g] = (float)m;
+    }
+    if ((rc = tz_search_improved_policy_each(ra->search, mvc.data(), w, pol.data()))) return rc;  // :196-202
+    if ((rc = tz_search_ube_target(ra->search, BETA, ube.data()))) return rc;                     // :203
+    std::vector<int32_t> nm(B);
+    std::vector<uint16_t> mv_pad((size_t)B * ra->amax, 0);
+    std::vector<float> pol_pad((size_t)B * ra->amax, 0.0f);
+    uint64_t total_moves = 0;
+    for (int g = 0; g < B; g++) {
+        const int nc = (int)info[g].n_children;
+        nm[g] = nc;
+        total_moves += (uint64_t)nc;
+        memcpy(&mv_pad[(size_t)g * ra->amax], &moves[(size_t)g * w], sizeof(uint16_t) * nc);
+        memcpy(&pol_pad[(size_t)g * ra->amax], &pol[(size_t)g * w], sizeof(float) * nc);
+        if (info[g].eval_tag != TZ_EVAL_VALUE) {  // solved root: its own evaluation (:184-187)
+            value[g] = eval_to_f32(info[g].eval_tag, info[g].eval.ply);
+        } else {                                   // minus the selected child's evaluation (:188-195)
+            float v = 0.0f;
+            for (int i = 0; i < nc; i++)
+                if (moves[(size_t)g * w + i] == selected[g]) {
+                    const size_t o = (size_t)g * w + i;
+                    v = tag[o] == TZ_EVAL_VALUE ? tz_bits_to_float(bits[o]) : eval_to_f32(tag[o], bits[o]);
+                    break;
+                }
+            value[g] = -v;
+        }
+    }
+    std::vector<char> out((size_t)B * 200 + total_moves * 40);
+    uint64_t written = 0;
+    if ((rc = tz_format_targets(ra->n, B, states.data(), mv_pad.data(), pol_pad.data(), nm.data(), ra->amax, value.data(), ube.data(),
+                                out.data(), out.size(), &written)))
+        return rc;
+    ra->targets_text.append(out.data(), written);
+    ra->n_targets += (uint64_t)B;
+    return TZ_OK;
+}
+
+int tz_reanalyze_take_text(tz_reanalyze* ra, char* out, uint64_t cap, uint64_t* size_out) {
+    if (!ra || !size_out) return tz_fail(TZ_EINVAL, "tz_reanalyze_take_text: bad argument");
+    *size_out = ra->targets_text.size();
+    if (!out || cap < ra->targets_text.size()) return ra->targets_text.empty() ? TZ_OK : TZ_ECAPACITY;
+    memcpy(out, ra->targets_text.data(), ra->targets_text.size());
+    ra->targets_text.clear();
+    return TZ_OK;
+}
+
+// reanalyze::main on a directory for `iterations` outer iterations (< 0: forever).  min_positions <= 0: the
+// reference's 128 000; wait_limit_s < 0: wait forever.
+int tz_reanalyze_run(tz_reanalyze* ra, const char* directory, int iterations, int min_positions, const char* suffix,
+                     int (*reload)(void*), void* reload_user, double wait_limit_s) {
+    if (!ra || !directory) return tz_fail(TZ_EINVAL, "tz_reanalyze_run: bad argument");
+    const std::string dir = directory, suf = suffix ? suffix : "";
+    const int need = std::max(min_positions > 0 ? min_positions : MIN_POSITIONS, ra->B);
+    const bool fast = wait_limit_s >= 0 && wait_limit_s < 5;
+    double waited = 0.0;
+    auto nap = [&]() {
+        std::this_thread::sleep_for(std::chrono::milliseconds(fast ? 10 : 1000));
+        waited += fast ? 0.01 : 1.0;
+    };
+    int rc = TZ_OK;
+    for (int it = 0; iterations < 0 || it < iterations;) {
+        long a = -1, b = -1, c = -1;
+        FILE* f = fopen((dir + "/buffer_lengths.txt").c_str(), "rb");
+        const bool ok = f && fscanf(f, "%ld,%ld,%ld", &a, &b, &c) == 3 && a + b == c;
+        if (f) fclose(f);
+        if (!ok || b > MAX_REANALYZE_BUFFER_LEN) {
+            if (wait_limit_s >= 0 && waited >= wait_limit_s)
+                return tz_fail(TZ_ESTATE, ok ? "tz_reanalyze_run: learn's buffer stayed over its cap" : "tz_reanalyze_run: buffer_lengths.txt unreadable");
+            nap();
+            continue;
+        }
+        if (reload && (rc = reload(reload_user))) return rc;
+        uint64_t added = 0, total = 0;
+        (void)tz_reanalyze_feed(ra, (dir + "/replays.txt").c_str(), &added, &total);  // "Cannot fill position buffer": keep going
+        if ((int64_t)ra->positions.size() < need) {
+            if (wait_limit_s >= 0 && waited >= wait_limit_s) return tz_fail(TZ_ESTATE, "tz_reanalyze_run: not enough positions yet");
+            nap();  // the reference sleeps 60 s here (:135-142)
+            continue;
+        }
+        if ((rc = tz_reanalyze_iterate(ra))) return rc;
+        FILE* out = fopen((dir + "/targets-reanalyze" + suf + ".txt").c_str(), "ab");
+        if (!out || fwrite(ra->targets_text.data(), 1, ra->targets_text.size(), out) != ra->targets_text.size()) {
+            if (out) fclose(out);
+            return tz_fail(TZ_ESTATE, "tz_reanalyze_run: cannot append targets-reanalyze");
+        }
+        fclose(out);
+        ra->targets_text.clear();
+        it++;
+    }
+    return rc;
+}
+
+}  // extern "C"

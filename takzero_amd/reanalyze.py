@@ -124,3 +124,83 @@ class Reanalyze:
                 value = -api.eval_to_f32(ch["eval_tag"][g, j], ch["eval_bits"][g, j])
             targets.append((states[g], ch["move_idx"][g, :nc].copy(), pol[g, :nc].copy(), float(value), float(ube[g])))
         return targets
+
+
+class NativeReanalyze:
+    """The same driver in native code (csrc/tz_host.cpp, tz_reanalyze_*): position buffer, sampling, search and target
+    lines below the ABI; this class only forwards."""
+
+    KINDS = {"puct": 0, "gumbel": 1}
+
+    def __init__(self, mcts, sims, seed=0, rank=0, world=1, search="puct", sampled_actions=64):
+        import ctypes as C
+
+        from . import _lib
+
+        self.mcts, self.lib = mcts, _lib.load()
+        self.h = C.c_void_p()
+        _lib.check(self.lib.tz_reanalyze_create(mcts.h, sims, seed, rank, world, self.KINDS[search], sampled_actions, C.byref(self.h)))
+        self.positions = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tz_reanalyze_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, path):
+        """fill_buffer_with_positions_from_replays: positions added from what was appended to `path`."""
+        import ctypes as C
+
+        from . import _lib
+
+        added, total = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.tz_reanalyze_feed(self.h, str(path).encode(), C.byref(added), C.byref(total)))
+        self.positions = total.value
+        return added.value
+
+    def iterate(self):
+        from . import _lib
+
+        _lib.check(self.lib.tz_reanalyze_iterate(self.h))
+
+    def take_text(self):
+        import ctypes as C
+
+        from . import _lib
+
+        size = C.c_uint64()
+        self.lib.tz_reanalyze_take_text(self.h, None, 0, C.byref(size))
+        if size.value == 0:
+            return b""
+        buf = C.create_string_buffer(size.value)
+        _lib.check(self.lib.tz_reanalyze_take_text(self.h, buf, size.value, C.byref(size)))
+        return buf.raw[:size.value]
+
+    def run(self, directory, iterations=None, min_positions=0, suffix="", reload=None, wait_limit_s=-1.0):
+        import ctypes as C
+
+        from . import _lib
+
+        cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p)
+        failure = []
+
+        def trampoline(_user):
+            try:
+                reload()
+                return 0
+            except Exception as e:
+                failure.append(e)
+                return -6
+
+        cb = cb_type(trampoline) if reload is not None else None
+        rc = self.lib.tz_reanalyze_run(self.h, str(directory).encode(), -1 if iterations is None else iterations, min_positions,
+                                       suffix.encode(), C.cast(cb, C.c_void_p) if cb is not None else None, None, wait_limit_s)
+        if failure:
+            raise failure[0]
+        _lib.check(rc)

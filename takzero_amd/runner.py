@@ -288,10 +288,37 @@ def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, wor
 
 
 def run_reanalyze(directory, mcts, sims, iterations=None, seed=0, rank=0, world=1, search="gumbel",
-                  sampled_actions=64, min_positions=MIN_POSITIONS, watch_model=True, sleep=1.0, max_wait=None,
+                  sampled_actions=64, min_positions=MIN_POSITIONS, watch_model=True, native=False, sleep=1.0, max_wait=None,
                   log=None):
     """reanalyze::main (reanalyze/src/main.rs:60-244) for `iterations` outer iterations (None = forever)."""
     n = mcts.n
+    if native:   # the whole loop below the ABI (csrc/tz_host.cpp)
+        from .reanalyze import NativeReanalyze
+
+        nra = NativeReanalyze(mcts, sims, seed=seed, rank=rank, world=world, search=search, sampled_actions=sampled_actions)
+        watcher = ModelWatcher(mcts.agent, directory) if watch_model else None
+
+        def reload():
+            t0 = time.monotonic()
+            while True:   # reanalyze retries every kind of load failure (reanalyze/src/main.rs:93-105)
+                try:
+                    watcher.refresh()
+                    return
+                except Exception as err:
+                    if log:
+                        log("Cannot load model: %s, retrying." % err)
+                    if max_wait is not None and time.monotonic() - t0 > max_wait:
+                        raise
+                    time.sleep(sleep)
+
+        try:
+            nra.run(directory, iterations=iterations, min_positions=min_positions, suffix="" if world == 1 else "-rank%d" % rank,
+                    reload=reload if watcher is not None else None, wait_limit_s=-1.0 if max_wait is None else float(max_wait))
+        except _lib_error() as e:
+            if e.code == -6:
+                raise TimeoutError(str(e))
+            raise
+        return nra
     ra = Reanalyze(mcts, sims, seed=seed, rank=rank, world=world, search=search, sampled_actions=sampled_actions)
     watcher = ModelWatcher(mcts.agent, directory) if watch_model else None
     suffix = "" if world == 1 else "-rank%d" % rank

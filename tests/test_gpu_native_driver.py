@@ -107,3 +107,54 @@ def test_native_directory_loop_with_exploration_and_back_pressure(oracle, tmp_pa
     with pytest.raises(TimeoutError):
         R.run_selfplay(d, mcts, 16, moves=1, watch_model=False, native=True, max_wait=0.1)
     assert os.path.getsize(os.path.join(d, "replays.txt")) == before
+
+
+def test_native_reanalyze_feeds_samples_and_writes_targets(oracle, tmp_path):
+    """tz_reanalyze_*: the native position buffer holds exactly the positions the Python one derives from the same
+    replay file (deterministic, no draws involved); an iteration gives one valid target line per sampled position;
+    ranks split the replay lines; the directory loop appends targets-reanalyze.txt."""
+    A = require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import reanalyze as RA
+    from takzero_amd import runner as R
+    from takzero_amd import selfplay as SP
+
+    d, n = str(tmp_path), 4
+    net, mcts = _setup(A, n, B=32)
+    sp = SP.NativeSelfPlay(mcts, 12, seed=1, search="puct")
+    for _ in range(60):
+        sp.play_move()
+    rpath = os.path.join(d, "replays.txt")
+    replays = sp.take_text(1)
+    open(rpath, "wb").write(replays + b"[TPS \"x4/x4/x4/x4 1 1\"] a1 a1\nnot a replay\n[TPS \"x4/x4/x4/x4 1 1\"] a1 b")  # illegal, junk, half
+    ref = RA.PositionBuffer(mcts, n, 4)
+    want = ref.read_new(rpath)
+    nat = RA.NativeReanalyze(mcts, 16, seed=2, search="gumbel", sampled_actions=4)
+    assert nat.feed(rpath) == want == nat.positions and nat.feed(rpath) == 0
+    with open(rpath, "ab") as f:
+        f.write(b"1\n")                        # the half-written line is completed ("a1 b1"): one more replay, two positions
+    assert nat.feed(rpath) == ref.read_new(rpath) == 2
+    for search, sims in (("gumbel", 16), ("puct", 24)):
+        nat2 = RA.NativeReanalyze(mcts, sims, seed=3, search=search, sampled_actions=4)
+        nat2.feed(rpath)
+        nat2.iterate()
+        lines = nat2.take_text().decode().splitlines(keepends=True)
+        assert len(lines) == mcts.batch and nat2.take_text() == b""
+        for line in lines:
+            st, mv, pol, value, ube = F.parse_target(line, n, 4)
+            legal = O.possible_moves(oracle, O.TzState.from_buffer_copy(np.array([st]).tobytes()))
+            assert [int(m) for m in mv] == list(legal)
+            assert abs(float(pol.sum(dtype=np.float64)) - 1.0) < 1e-3 and -1.0 <= value <= 1.0 and 0.0 <= ube <= 4.0
+    a = RA.NativeReanalyze(mcts, 16, seed=2, rank=0, world=2)
+    b = RA.NativeReanalyze(mcts, 16, seed=2, rank=1, world=2)
+    assert a.feed(rpath) + b.feed(rpath) == nat.positions and a.positions > 0 and b.positions > 0
+    # the directory loop
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    nra = R.run_reanalyze(d, mcts, 16, iterations=2, seed=4, search="gumbel", sampled_actions=4, min_positions=64,
+                          watch_model=False, native=True, max_wait=5)
+    out = open(os.path.join(d, "targets-reanalyze.txt")).read().splitlines()
+    assert len(out) == 2 * mcts.batch
+    assert nra.feed(rpath) == 0   # the loop has consumed the whole replay file
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, R.MAX_REANALYZE_BUFFER_LEN + 1))
+    with pytest.raises(TimeoutError):
+        R.run_reanalyze(d, mcts, 16, iterations=1, watch_model=False, native=True, min_positions=64, max_wait=0.1)
