@@ -74,6 +74,39 @@ def config5(games=4096, sims=1600, selfplay_moves=40, iterations=1):
     return out
 
 
+def config5_native(games=4096, sims=1600, selfplay_moves=40, iterations=1):
+    """config 5 through the native drivers (csrc/tz_host.cpp): self-play writes replays.txt, reanalyze tails it."""
+    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
+    mcts = A.BatchedMCTS(games, 5, 4, agent=net)
+    sp = SP.NativeSelfPlay(mcts, 8, seed=1, search="puct")
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "replays.txt")
+    with open(path, "wb") as f:
+        for _ in range(selfplay_moves):
+            sp.play_move()
+            f.write(sp.take_text(1))
+    re = RA.NativeReanalyze(mcts, sims, seed=0, search="puct")
+    t0 = time.perf_counter()
+    npos = re.feed(path)
+    t_feed = time.perf_counter() - t0
+    if npos < games:
+        return {"config": "reanalyze (native)", "error": "only %d positions in the synthetic replay file" % npos}
+    mcts.sync()
+    s0, _ = mcts.counters()
+    t0 = time.perf_counter()
+    nt = 0
+    for _ in range(iterations):
+        re.iterate()
+        nt += re.take_text().count(b"\n")
+    mcts.sync()
+    dt = time.perf_counter() - t0
+    s1, _ = mcts.counters()
+    return {"config": "5x5 reanalyze through the native driver, %d positions/iteration, %d sims/position, net5" % (games, sims),
+            "replay_positions_in_buffer": npos, "feed_positions_per_s": npos / t_feed, "sims_per_s": (s1 - s0) / dt,
+            "targets_per_s": nt / dt}
+
+
 def gumbel(moves=3, games=4096, budget=768, k=64):
     """What the reference's selfplay binary runs today (selfplay/src/main.rs:138-153): Gumbel sequential halving,
     64 sampled actions, budget 768, on 5x5 / net5."""
@@ -126,6 +159,8 @@ def directory_loop(moves=100, games=4096, sims=400):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["4", "5"]
+    if "5n" in which:
+        print(json.dumps(config5_native()), flush=True)
     if "dir" in which:
         print(json.dumps(directory_loop()), flush=True)
     if "gumbel" in which:
