@@ -158,3 +158,36 @@ def test_native_reanalyze_feeds_samples_and_writes_targets(oracle, tmp_path):
     open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, R.MAX_REANALYZE_BUFFER_LEN + 1))
     with pytest.raises(TimeoutError):
         R.run_reanalyze(d, mcts, 16, iterations=1, watch_model=False, native=True, min_positions=64, max_wait=0.1)
+
+
+def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
+    """examples/selfplay_cli.cpp: the selfplay binary as a plain C++ program linked against libtakzero_hip.so — no
+    Python, no torch in the process.  It must produce the same kind of files, and pick up a new model_latest.tzw."""
+    import subprocess
+
+    A = require_gpu()
+    from takzero_amd import _lib
+    from takzero_amd import formats as F
+    from takzero_amd import weights as W
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "selfplay_cli")
+    r = subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(root, "examples", "selfplay_cli.cpp"), "-I" + os.path.join(root, "include"),
+                        "-L" + os.path.dirname(_lib.LIB_PATH), "-ltakzero_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the example here: " + r.stderr[-300:])
+    d, n = str(tmp_path), 4
+    W.save_tzw(os.path.join(d, "start.tzw"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=7))
+    W.save_tzw(os.path.join(d, "model_latest.tzw"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    r = subprocess.run([exe, "--directory", d, "--model", os.path.join(d, "start.tzw"), "--arch", "100", "--n", str(n), "--blocks", "1",
+                        "--games", "48", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel", "--moves", "60", "--wait-limit", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
+    fields = dict(zip(r.stdout.split()[::2], r.stdout.split()[1::2]))
+    assert fields["moves"] == "60" and fields["model_reloads"] == "1" and int(fields["replays"]) > 0
+    targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
+    replays = open(os.path.join(d, "replays.txt"), "rb").read()
+    assert targets.count(b"\n") == int(fields["targets"]) and replays.count(b"\n") == int(fields["replays"])
+    _check_lines(oracle, n, targets, replays, "gumbel")
