@@ -7,6 +7,7 @@
 //   ./selfplay_cli --directory DIR --model DIR/model_latest.tzw --arch 5 --games 128 --sims 768 --search gumbel
 #include <sys/stat.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -86,12 +87,14 @@ int main(int argc, char** argv) {
     CHECK(tz_search_create(net, TZ_AGENT_NET, games, n, 4, 0, &mcts));
     CHECK(tz_selfplay_create(mcts, sims, 0, 0, search == "puct" ? 0 : 1, k, exploration, &sp));
     Reload reload{net, directory + "/model_latest.tzw"};
+    const auto t0 = std::chrono::steady_clock::now();
     CHECK(tz_selfplay_run(sp, directory.c_str(), moves, 32000, "", reload_model, &reload, wait_limit));
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     unsigned long long played = 0, targets = 0, replays = 0, simulations = 0, evals = 0;
     CHECK(tz_selfplay_counters(sp, (uint64_t*)&played, (uint64_t*)&targets, (uint64_t*)&replays));
     CHECK(tz_search_counters(mcts, (uint64_t*)&simulations, (uint64_t*)&evals));
-    printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d\n", played, targets, replays,
-           simulations, evals, reload.reloads);
+    printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f\n", played,
+           targets, replays, simulations, evals, reload.reloads, seconds, (double)simulations / seconds);
     tz_selfplay_destroy(sp);
     tz_search_destroy(mcts);
     tz_net_destroy(net);
