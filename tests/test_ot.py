@@ -68,3 +68,21 @@ def test_net_load_ot_equals_load_tensors(ot_writer, tmp_path):
     for x, y in zip(ra, rb):
         assert np.array_equal(np.asarray(x), np.asarray(y))
     assert np.array_equal(a.hash_indices(states), b.hash_indices(states))
+
+
+def test_update_rnd_persistance(ot_writer, tmp_path):
+    """net5.rs:327-347 `update_rnd_persistance`: the RND normalisation (min / max variables of the VarStore) survives a
+    save / load of the full net5 archive, as do all 28.8 M parameters."""
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_NET5, seed=4)
+    assert w["min"].tolist() == [0.0] and w["max"].tolist() == [1.0]   # net5.rs:166-168
+    w["min"] = np.float32([0.25])
+    w["max"] = np.float32([7.5])
+    path = ot.save_ot(tmp_path / "model_latest.ot", w)
+    back = ot.load_ot(path)
+    assert back["min"].tolist() == [0.25] and back["max"].tolist() == [7.5]
+    assert set(back) == set(w) and sum(v.size for v in back.values()) == sum(v.size for v in w.values())
+    for k in ("rnd_target.final_linear.weight", "core.res_block_19.b.batch_norm.running_var", "policy.conv2d.bias"):
+        assert np.array_equal(back[k], w[k]), k
