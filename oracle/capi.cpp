@@ -144,6 +144,8 @@ struct tzo_search {
     int n, half_komi;
     std::unique_ptr<BatchedMCTS<TakEnv>> mcts;
     std::unique_ptr<Agent<TakEnv>> agent;
+    std::vector<int8_t> term_reason;   // of the games the last restart_terminal found finished
+    std::vector<uint8_t> term_winner;
 };
 
 tzo_search* tzo_search_create(int agent_kind, tzo_agent_fn fn, void* user, int batch, int n, int half_komi) {
@@ -264,10 +266,15 @@ int tzo_search_step(tzo_search* s, const uint16_t* actions) {
     return 0;
 }
 int tzo_search_restart_terminal(tzo_search* s, const int32_t* choice, int8_t* terminal_out) {
+    s->term_reason.assign(s->mcts->batch(), 0);
+    s->term_winner.assign(s->mcts->batch(), 0);
     for (size_t g = 0; g < s->mcts->batch(); g++) {
         int t = s->mcts->envs[g].terminal();
         terminal_out[g] = (int8_t)t;
         if (t != TZ_TERMINAL_NONE) {
+            const Result r = s->mcts->envs[g].g.result();
+            s->term_reason[g] = (int8_t)s->mcts->envs[g].g.result_reason();
+            s->term_winner[g] = r == WHITE_WINS ? 0 : r == BLACK_WINS ? 1 : 2;
             s->mcts->envs[g].g = new_opening(s->n, s->half_komi, choice[g]);
             s->mcts->nodes[g] = Node<TakEnv>();
             s->mcts->replays[g].clear();
@@ -284,6 +291,52 @@ int tzo_search_gumbel_sh(tzo_search* s, const float* betas, int sampled_actions,
     std::vector<int> sel;
     s->mcts->gumbel_sequential_halving(*s->agent, b, (size_t)sampled_actions, (uint32_t)search_budget, g, sel);
     for (size_t i = 0; i < B; i++) selected_out[i] = (uint16_t)sel[i];
+    return 0;
+}
+// the rest of the search ABI, so that a driver written against tz_search_* can run over this oracle unchanged
+int tzo_search_shape(tzo_search* s, int* batch_out, int* n_out, int* half_komi_out, int* max_actions_out) {
+    if (batch_out) *batch_out = (int)s->mcts->batch();
+    if (n_out) *n_out = s->n;
+    if (half_komi_out) *half_komi_out = s->half_komi;
+    if (max_actions_out) *max_actions_out = s->n <= 3 ? 64 : s->n == 4 ? 192 : s->n == 5 ? 512 : 1024;
+    return 0;
+}
+int tzo_search_terminal_details(tzo_search* s, int8_t* reason_out, uint8_t* winner_out) {
+    for (size_t g = 0; g < s->mcts->batch(); g++) {
+        reason_out[g] = g < s->term_reason.size() ? s->term_reason[g] : 0;
+        winner_out[g] = g < s->term_winner.size() ? s->term_winner[g] : 0;
+    }
+    return 0;
+}
+int tzo_search_improved_policy_each(tzo_search* s, const float* visitations, int amax, float* out) {
+    std::vector<float> p;
+    for (size_t g = 0; g < s->mcts->batch(); g++) {
+        s->mcts->nodes[g].improved_policy(visitations[g], p);
+        if ((int)p.size() > amax) return -1;
+        for (int i = 0; i < amax; i++) out[g * amax + i] = i < (int)p.size() ? p[i] : 0.0f;
+    }
+    return 0;
+}
+// validated move application (Replay::from_str / Replay::states): 1 applied, 0 illegal or none, -1 already terminal
+int tzo_search_play_moves(tzo_search* s, const uint16_t* actions, int8_t* ok_out) {
+    for (size_t g = 0; g < s->mcts->batch(); g++) {
+        Game& game = s->mcts->envs[g].g;
+        s->mcts->nodes[g] = Node<TakEnv>();
+        if (game.terminal() != TZ_TERMINAL_NONE) {
+            ok_out[g] = -1;
+            continue;
+        }
+        ok_out[g] = 0;
+        if (actions[g] == 0xFFFF) continue;
+        std::vector<Move> legal;
+        game.possible_moves(legal);
+        for (const Move& m : legal)
+            if (move_index(s->n, m) == (int)actions[g]) {
+                game.play(m);
+                ok_out[g] = 1;
+                break;
+            }
+    }
     return 0;
 }
 int tzo_search_counters(tzo_search* s, uint64_t* sims, uint64_t* evals) {

@@ -446,6 +446,19 @@ struct Game {
         return ONGOING;
     }
 
+    // why the game is over, for the PTN result of a Replay line (takparse GameResult, target.rs:226-230):
+    // 0 ongoing, 1 road, 2 flat count (board full / reserves empty), 3 reversible-plies draw
+    int result_reason() const {
+        if (result() == ONGOING) return 0;
+        if (ply > 0 && (has_road(0) || has_road(1))) return 1;
+        if (reversible_plies >= REVERSIBLE_PLIES_LIMIT) {
+            Game copy = *this;
+            copy.reversible_plies = 0;
+            if (copy.result() == ONGOING) return 3;
+        }
+        return 2;
+    }
+
     // Environment::terminal, takzero/src/search/env.rs:47-59
     int terminal() const {
         Result r = result();

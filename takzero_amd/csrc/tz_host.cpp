@@ -22,6 +22,13 @@
 #include "tz_engine.h"
 #include "tz_math.h"
 
+// Every call into the search goes through these two names, so that a test build can bind this same driver to another
+// implementation of the search ABI (the default is the HIP engine of this library).
+#ifndef TZS
+#define TZS(name) tz_search_##name
+#define TZ_SEARCH_T tz_search
+#endif
+
 namespace {
 
 constexpr float NOISE_ALPHA = 0.05f;          // selfplay/src/main.rs:39
@@ -66,7 +73,7 @@ const char* result_string(int reason, int winner) {  // takparse GameResult (tar
 }  // namespace
 
 struct tz_selfplay {
-    tz_search* search = nullptr;
+    TZ_SEARCH_T* search = nullptr;
     int B = 0, n = 0, half_komi = 0, amax = 0;
     int sims = 0, kind = 0, k = 64;
     std::vector<float> betas;
@@ -97,7 +104,7 @@ struct tz_selfplay {
 namespace {
 
 int fetch_children(tz_selfplay* sp, int* width_out) {
-    int rc = tz_search_root_info(sp->search, sp->info.data());
+    int rc = TZS(root_info)(sp->search, sp->info.data());
     if (rc) return rc;
     int w = 1;
     for (int g = 0; g < sp->B; g++) w = std::max(w, (int)sp->info[g].n_children);
@@ -107,13 +114,13 @@ int fetch_children(tz_selfplay* sp, int* width_out) {
     sp->c_tag.resize(cells);
     sp->c_bits.resize(cells);
     *width_out = w;
-    return tz_search_root_children(sp->search, w, sp->c_moves.data(), sp->c_visits.data(), sp->c_tag.data(), sp->c_bits.data(),
+    return TZS(root_children)(sp->search, w, sp->c_moves.data(), sp->c_visits.data(), sp->c_tag.data(), sp->c_bits.data(),
                                    nullptr, nullptr, nullptr);
 }
 
 // BatchedMCTS::select_actions_in_selfplay (batched.rs:165-183) / Node::select_selfplay_action (node/mod.rs:170-207)
 int select_actions_in_selfplay(tz_selfplay* sp, std::vector<uint16_t>& out) {
-    int rc = tz_search_select_best_actions(sp->search, sp->best.data());
+    int rc = TZS(select_best_actions)(sp->search, sp->best.data());
     if (rc) return rc;
     out = sp->best;
     int w = 0;
@@ -206,7 +213,7 @@ int record(tz_selfplay* sp) {  // take_a_step up to the step itself (selfplay/sr
     const int B = sp->B;
     m.width = w;
     m.states.resize(B);
-    if ((rc = tz_search_get_positions(sp->search, m.states.data()))) return rc;
+    if ((rc = TZS(get_positions)(sp->search, m.states.data()))) return rc;
     m.moves = sp->c_moves;
     m.pol.assign((size_t)B * w, 0.0f);
     m.nchild.resize(B);
@@ -228,11 +235,11 @@ int record(tz_selfplay* sp) {  // take_a_step up to the step itself (selfplay/sr
         int lg = 0;
         while ((1 << (lg + 1)) <= sp->k) lg++;
         const float visitations = (float)((sp->sims / lg / sp->k) * ((1 << lg) - 1));
-        if ((rc = tz_search_improved_policy(sp->search, visitations, w, m.pol.data()))) return rc;
+        if ((rc = TZS(improved_policy)(sp->search, visitations, w, m.pol.data()))) return rc;
     }
     if (sp->kind == 2) {
         for (int g = 0; g < B; g++) m.ube[g] = 4.0f - 1.1920929e-07f;  // MAXIMUM_VARIANCE - f32::EPSILON (learn/src/main.rs:460)
-    } else if ((rc = tz_search_ube_target(sp->search, BETA, m.ube.data()))) {
+    } else if ((rc = TZS(ube_target)(sp->search, BETA, m.ube.data()))) {
         return rc;
     }
     for (int g = 0; g < B; g++) {
@@ -256,8 +263,8 @@ int complete(tz_selfplay* sp) {  // restart_envs_and_complete_targets (selfplay/
     if (any) {
         int rc;
         std::vector<tz_state> fresh(B);
-        if ((rc = tz_search_get_positions(sp->search, fresh.data()))) return rc;
-        if ((rc = tz_search_terminal_details(sp->search, sp->reason.data(), sp->winner.data()))) return rc;
+        if ((rc = TZS(get_positions)(sp->search, fresh.data()))) return rc;
+        if ((rc = TZS(terminal_details)(sp->search, sp->reason.data(), sp->winner.data()))) return rc;
         const int amax = sp->amax;
         char buf[256];
         std::vector<uint16_t> acts;
@@ -346,14 +353,14 @@ extern "C" {
 // search_kind: 0 = PUCT + Dirichlet (the north star's loop, selfplay/src/main.rs:127-136), 1 = Gumbel sequential
 // halving with `sampled_actions` (:138-153), 2 = uniformly random legal moves (learn's pre-training games).
 // exploration != 0: the first half of the games search with beta = 0.25 (cargo feature "exploration", :79-86).
-int tz_selfplay_create(tz_search* search, int sims_per_move, uint64_t seed, int shard, int search_kind, int sampled_actions,
+int tz_selfplay_create(TZ_SEARCH_T* search, int sims_per_move, uint64_t seed, int shard, int search_kind, int sampled_actions,
                        int exploration, tz_selfplay** out) {
     if (!search || !out || search_kind < 0 || search_kind > 2 || sims_per_move < 0)
         return tz_fail(TZ_EINVAL, "tz_selfplay_create: bad argument");
     *out = nullptr;
     std::unique_ptr<tz_selfplay> sp(new tz_selfplay());
     sp->search = search;
-    int rc = tz_search_shape(search, &sp->B, &sp->n, &sp->half_komi, &sp->amax);
+    int rc = TZS(shape)(search, &sp->B, &sp->n, &sp->half_komi, &sp->amax);
     if (rc) return rc;
     sp->sims = sims_per_move;
     sp->kind = search_kind;
@@ -376,8 +383,8 @@ int tz_selfplay_create(tz_search* search, int sims_per_move, uint64_t seed, int 
     sp->winner.resize(B);
     std::uniform_int_distribution<int> open(0, 15);
     for (int g = 0; g < B; g++) sp->choice[g] = open(sp->rng);
-    if ((rc = tz_search_new_openings(search, sp->choice.data()))) return rc;
-    if ((rc = tz_search_get_positions(search, sp->start_states.data()))) return rc;
+    if ((rc = TZS(new_openings)(search, sp->choice.data()))) return rc;
+    if ((rc = TZS(get_positions)(search, sp->start_states.data()))) return rc;
     *out = sp.release();
     return TZ_OK;
 }
@@ -394,16 +401,16 @@ int tz_selfplay_play_move(tz_selfplay* sp) {
     const int B = sp->B;
     int rc, w = 0;
     if (sp->kind == 0) {
-        if ((rc = tz_search_simulate(sp->search, sp->betas.data(), 1))) return rc;            // :128
-        if ((rc = tz_search_root_info(sp->search, sp->info.data()))) return rc;
+        if ((rc = TZS(simulate)(sp->search, sp->betas.data(), 1))) return rc;            // :128
+        if ((rc = TZS(root_info)(sp->search, sp->info.data()))) return rc;
         w = 1;
         for (int g = 0; g < B; g++) w = std::max(w, (int)sp->info[g].n_children);
         dirichlet_rows(sp, w);
-        if ((rc = tz_search_apply_noise(sp->search, sp->noise.data(), w, NOISE_RATIO))) return rc;  // :131
-        if ((rc = tz_search_simulate(sp->search, sp->betas.data(), sp->sims))) return rc;        // :134-136
+        if ((rc = TZS(apply_noise)(sp->search, sp->noise.data(), w, NOISE_RATIO))) return rc;  // :131
+        if ((rc = TZS(simulate)(sp->search, sp->betas.data(), sp->sims))) return rc;        // :134-136
         if ((rc = select_actions_in_selfplay(sp, sp->actions))) return rc;                        // batched.rs:165-183
     } else if (sp->kind == 2) {
-        if ((rc = tz_search_simulate(sp->search, sp->betas.data(), 1))) return rc;
+        if ((rc = TZS(simulate)(sp->search, sp->betas.data(), 1))) return rc;
         if ((rc = fetch_children(sp, &w))) return rc;
         std::uniform_real_distribution<double> uni(0.0, 1.0);
         for (int g = 0; g < B; g++) {
@@ -419,9 +426,9 @@ int tz_selfplay_play_move(tz_selfplay* sp) {
             if (u <= 0.0) u = 1e-300;
             x = (float)(-std::log(-std::log(u)));  // Gumbel(0, 1)
         }
-        if ((rc = tz_search_gumbel_sh(sp->search, sp->betas.data(), sp->k, sp->sims, sp->gumbel.data(), sp->amax, sp->actions.data())))
+        if ((rc = TZS(gumbel_sh)(sp->search, sp->betas.data(), sp->k, sp->sims, sp->gumbel.data(), sp->amax, sp->actions.data())))
             return rc;                                                                           // :138-144
-        if ((rc = tz_search_root_info(sp->search, sp->info.data()))) return rc;
+        if ((rc = TZS(root_info)(sp->search, sp->info.data()))) return rc;
         bool early = false;
         for (int g = 0; g < B; g++) early = early || sp->info[g].ply < WEIGHTED_RANDOM_PLIES;
         if (early) {                                                                             // :145-153
@@ -434,10 +441,10 @@ int tz_selfplay_play_move(tz_selfplay* sp) {
         }
     }
     if ((rc = record(sp))) return rc;
-    if ((rc = tz_search_step(sp->search, sp->actions.data()))) return rc;                        // take_a_step
+    if ((rc = TZS(step)(sp->search, sp->actions.data()))) return rc;                        // take_a_step
     std::uniform_int_distribution<int> open(0, 15);
     for (int g = 0; g < B; g++) sp->choice[g] = open(sp->rng);
-    if ((rc = tz_search_restart_terminal(sp->search, sp->choice.data(), sp->term.data()))) return rc;
+    if ((rc = TZS(restart_terminal)(sp->search, sp->choice.data(), sp->term.data()))) return rc;
     if ((rc = complete(sp))) return rc;
     sp->moves_played++;
     sp->positions += (uint64_t)B;
@@ -556,7 +563,7 @@ constexpr int MAX_REANALYZE_BUFFER_LEN = 32000;  // :40
 }  // namespace
 
 struct tz_reanalyze {
-    tz_search* search = nullptr;
+    TZ_SEARCH_T* search = nullptr;
     int B = 0, n = 0, half_komi = 0, amax = 0;
     int sims = 0, kind = 0, k = 64, rank = 0, world = 1;
     std::mt19937_64 rng;
@@ -618,7 +625,7 @@ int expand_replays(tz_reanalyze* ra, const std::vector<ParsedReplay>& replays, u
             idx[g] = g;
             states[g] = replays[base + g].start;
         }
-        int rc = tz_search_set_positions(ra->search, cnt, idx.data(), states.data());
+        int rc = TZS(set_positions)(ra->search, cnt, idx.data(), states.data());
         if (rc) return rc;
         std::vector<std::vector<tz_state>> per_game(cnt);
         std::vector<char> alive(B, 0), dropped(cnt, 0);
@@ -635,8 +642,8 @@ int expand_replays(tz_reanalyze* ra, const std::vector<ParsedReplay>& replays, u
                 }
             }
             if (!any) break;
-            if ((rc = tz_search_get_positions(ra->search, cur.data()))) return rc;
-            if ((rc = tz_search_play_moves(ra->search, acts.data(), ok.data()))) return rc;
+            if ((rc = TZS(get_positions)(ra->search, cur.data()))) return rc;
+            if ((rc = TZS(play_moves)(ra->search, acts.data(), ok.data()))) return rc;
             for (int g = 0; g < cnt; g++) {
                 if (!alive[g]) continue;
                 if (ok[g] == 1) {
@@ -663,14 +670,14 @@ extern "C" {
 
 // search_kind: 0 = `sims` PUCT simulations per position (SURVEY config 5), 1 = Gumbel sequential halving with budget
 // `sims` and `sampled_actions` (reanalyze/src/main.rs:171-177).  rank / world: replay line i belongs to rank i % world.
-int tz_reanalyze_create(tz_search* search, int sims, uint64_t seed, int rank, int world, int search_kind, int sampled_actions,
+int tz_reanalyze_create(TZ_SEARCH_T* search, int sims, uint64_t seed, int rank, int world, int search_kind, int sampled_actions,
                         tz_reanalyze** out) {
     if (!search || !out || sims <= 0 || world <= 0 || rank < 0 || rank >= world || search_kind < 0 || search_kind > 1)
         return tz_fail(TZ_EINVAL, "tz_reanalyze_create: bad argument");
     *out = nullptr;
     std::unique_ptr<tz_reanalyze> ra(new tz_reanalyze());
     ra->search = search;
-    int rc = tz_search_shape(search, &ra->B, &ra->n, &ra->half_komi, &ra->amax);
+    int rc = TZS(shape)(search, &ra->B, &ra->n, &ra->half_komi, &ra->amax);
     if (rc) return rc;
     ra->sims = sims;
     ra->kind = search_kind;
@@ -738,13 +745,13 @@ int tz_reanalyze_iterate(tz_reanalyze* ra) {
     }
     std::vector<int32_t> idx(B);
     for (int g = 0; g < B; g++) idx[g] = g;
-    int rc = tz_search_set_positions(ra->search, B, idx.data(), states.data());
+    int rc = TZS(set_positions)(ra->search, B, idx.data(), states.data());
     if (rc) return rc;
     std::vector<float> zero_beta(B, 0.0f);
     std::vector<uint16_t> selected(B);
     if (ra->kind == 0) {
-        if ((rc = tz_search_simulate(ra->search, zero_beta.data(), ra->sims))) return rc;
-        if ((rc = tz_search_select_best_actions(ra->search, selected.data()))) return rc;
+        if ((rc = TZS(simulate)(ra->search, zero_beta.data(), ra->sims))) return rc;
+        if ((rc = TZS(select_best_actions)(ra->search, selected.data()))) return rc;
     } else {
         std::vector<float> gumbel((size_t)B * ra->amax);
         std::uniform_real_distribution<double> uni(0.0, 1.0);
@@ -753,17 +760,17 @@ int tz_reanalyze_iterate(tz_reanalyze* ra) {
             if (u <= 0.0) u = 1e-300;
             x = (float)(-std::log(-std::log(u)));
         }
-        if ((rc = tz_search_gumbel_sh(ra->search, zero_beta.data(), ra->k, ra->sims, gumbel.data(), ra->amax, selected.data()))) return rc;
+        if ((rc = TZS(gumbel_sh)(ra->search, zero_beta.data(), ra->k, ra->sims, gumbel.data(), ra->amax, selected.data()))) return rc;
     }
     std::vector<tz_root_info> info(B);
-    if ((rc = tz_search_root_info(ra->search, info.data()))) return rc;
+    if ((rc = TZS(root_info)(ra->search, info.data()))) return rc;
     int w = 1;
     for (int g = 0; g < B; g++) w = std::max(w, (int)info[g].n_children);
     const size_t cells = (size_t)B * w;
     std::vector<uint16_t> moves(cells);
     std::vector<uint32_t> visits(cells), bits(cells);
     std::vector<uint8_t> tag(cells);
-    if ((rc = tz_search_root_children(ra->search, w, moves.data(), visits.data(), tag.data(), bits.data(), nullptr, nullptr, nullptr)))
+    if ((rc = TZS(root_children)(ra->search, w, moves.data(), visits.data(), tag.data(), bits.data(), nullptr, nullptr, nullptr)))
         return rc;
     std::vector<float> mvc(B), pol(cells), ube(B), value(B);
     for (int g = 0; g < B; g++) {  // most_visited_count (node/mod.rs:209-213)
@@ -771,8 +778,8 @@ int tz_reanalyze_iterate(tz_reanalyze* ra) {
         for (int i = 0; i < (int)info[g].n_children; i++) m = std::max(m, visits[(size_t)g * w + i]);
         mvc[g] = (float)m;
     }
-    if ((rc = tz_search_improved_policy_each(ra->search, mvc.data(), w, pol.data()))) return rc;  // :196-202
-    if ((rc = tz_search_ube_target(ra->search, BETA, ube.data()))) return rc;                     // :203
+    if ((rc = TZS(improved_policy_each)(ra->search, mvc.data(), w, pol.data()))) return rc;  // :196-202
+    if ((rc = TZS(ube_target)(ra->search, BETA, ube.data()))) return rc;                     // :203
     std::vector<int32_t> nm(B);
     std::vector<uint16_t> mv_pad((size_t)B * ra->amax, 0);
     std::vector<float> pol_pad((size_t)B * ra->amax, 0.0f);

@@ -1,0 +1,34 @@
+"""Builds and runs tests/host_over_oracle.cpp: the native host drivers (csrc/tz_host.cpp) bound to the CPU oracle."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(out_dir, sanitize):
+    exe = os.path.join(str(out_dir), "host_over_oracle" + ("_san" if sanitize else ""))
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "takzero_amd", "csrc"),
+           os.path.join(ROOT, "tests", "host_over_oracle.cpp"), os.path.join(ROOT, "oracle", "capi.cpp"),
+           os.path.join(ROOT, "takzero_amd", "csrc", "tz_text.cpp"), "-lpthread", "-o", exe]
+    if sanitize:
+        cmd[4:4] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the harness here: " + r.stderr[-400:])
+    return exe
+
+
+def run(exe, prefix, n, half_komi, agent, batch, kind, sims, k, exploration, moves, seed):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe] + [str(x) for x in (n, half_komi, agent, batch, kind, sims, k, exploration, moves, seed)] + [str(prefix)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-2000:])
+    out = {}
+    for part in ("targets", "replays", "exploration", "reanalyze"):
+        with open("%s.%s" % (prefix, part), "rb") as f:
+            out[part] = f.read()
+    out["positions"] = int(r.stdout.split()[1])
+    return out

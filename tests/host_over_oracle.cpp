@@ -1,0 +1,97 @@
+// Test harness: the native host drivers (takzero_amd/csrc/tz_host.cpp: selfplay::main and reanalyze::main) bound to
+// the CPU oracle's search (oracle/capi.cpp exposes the same surface under tzo_*) instead of the HIP engine.  Same
+// driver code, same seed => the text it produces over the oracle must equal, byte for byte, what it produces over the
+// GPU engine (tests/test_gpu_native_driver.py); and being pure CPU code it also runs under ASan / UBSan.
+//   host_over_oracle <n> <half_komi> <agent 1|2> <batch> <kind 0|1|2> <sims> <k> <exploration> <moves> <seed> <out prefix>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "takzero_hip.h"
+
+struct tzo_search;
+typedef void (*tzo_agent_fn)(void*, int, const tz_state*, const uint16_t*, const int32_t*, int, float*, float*, float*);
+extern "C" {
+tzo_search* tzo_search_create(int agent_kind, tzo_agent_fn fn, void* user, int batch, int n, int half_komi);
+void tzo_search_destroy(tzo_search* s);
+int tzo_search_shape(tzo_search* s, int*, int*, int*, int*);
+int tzo_search_set_positions(tzo_search* s, int count, const int32_t* game_idx, const tz_state* states);
+int tzo_search_get_positions(tzo_search* s, tz_state* out);
+int tzo_search_new_openings(tzo_search* s, const int32_t* choice);
+int tzo_search_simulate(tzo_search* s, const float* betas, int n_sims);
+int tzo_search_apply_noise(tzo_search* s, const float* noise, int amax, float ratio);
+int tzo_search_root_info(tzo_search* s, tz_root_info* out);
+int tzo_search_root_children(tzo_search* s, int amax, uint16_t* move_idx, uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits,
+                             float* logit, float* prob, float* std_dev);
+int tzo_search_select_best_actions(tzo_search* s, uint16_t* out);
+int tzo_search_improved_policy(tzo_search* s, float visitations, int amax, float* out);
+int tzo_search_improved_policy_each(tzo_search* s, const float* visitations, int amax, float* out);
+int tzo_search_ube_target(tzo_search* s, float beta, float* out);
+int tzo_search_step(tzo_search* s, const uint16_t* actions);
+int tzo_search_restart_terminal(tzo_search* s, const int32_t* choice, int8_t* terminal_out);
+int tzo_search_terminal_details(tzo_search* s, int8_t* reason_out, uint8_t* winner_out);
+int tzo_search_play_moves(tzo_search* s, const uint16_t* actions, int8_t* ok_out);
+int tzo_search_gumbel_sh(tzo_search* s, const float* betas, int sampled_actions, int search_budget, const float* gumbel, int amax,
+                         uint16_t* selected_out);
+}
+
+#define TZS(name) tzo_search_##name
+#define TZ_SEARCH_T tzo_search
+// the two constructors take the search handle: give this build's versions names of their own
+#define tz_selfplay_create tzh_selfplay_create
+#define tz_reanalyze_create tzh_reanalyze_create
+#include "../takzero_amd/csrc/tz_host.cpp"
+
+static void dump(const std::string& path, const std::string& text) {
+    FILE* f = fopen(path.c_str(), "wb");
+    fwrite(text.data(), 1, text.size(), f);
+    fclose(f);
+}
+
+int main(int argc, char** argv) {
+    if (argc != 12) return 2;
+    const int n = atoi(argv[1]), hk = atoi(argv[2]), agent = atoi(argv[3]), B = atoi(argv[4]), kind = atoi(argv[5]), sims = atoi(argv[6]),
+              k = atoi(argv[7]), exploration = atoi(argv[8]), moves = atoi(argv[9]);
+    const uint64_t seed = strtoull(argv[10], nullptr, 10);
+    const std::string prefix = argv[11];
+    tzo_search* s = tzo_search_create(agent, nullptr, nullptr, B, n, hk);
+    tz_selfplay* sp = nullptr;
+    if (tz_selfplay_create(s, sims, seed, 0, kind, k, exploration, &sp)) return 3;
+    std::string targets, replays, expl;
+    for (int m = 0; m < moves; m++) {
+        if (tz_selfplay_play_move(sp)) {
+            fprintf(stderr, "play_move: %s\n", tz_last_error());
+            return 4;
+        }
+        targets += sp->targets_text;
+        replays += sp->replays_text;
+        expl += sp->exploration_text;
+        sp->targets_text.clear();
+        sp->replays_text.clear();
+        sp->exploration_text.clear();
+    }
+    dump(prefix + ".targets", targets);
+    dump(prefix + ".replays", replays);
+    dump(prefix + ".exploration", expl);
+    tz_selfplay_destroy(sp);
+    // reanalyze over what was just played (searches from fresh trees, so it is independent of the loop above)
+    tz_reanalyze* ra = nullptr;
+    if (tz_reanalyze_create(s, kind == 1 ? sims : 32, seed + 1, 0, 1, kind == 1 ? 1 : 0, k, &ra)) return 5;
+    uint64_t added = 0, total = 0;
+    if (tz_reanalyze_feed(ra, (prefix + ".replays").c_str(), &added, &total)) return 6;
+    std::string re;
+    if (total >= (uint64_t)B) {
+        for (int it = 0; it < 2; it++) {
+            if (tz_reanalyze_iterate(ra)) {
+                fprintf(stderr, "iterate: %s\n", tz_last_error());
+                return 7;
+            }
+        }
+        re = ra->targets_text;
+    }
+    dump(prefix + ".reanalyze", re);
+    printf("positions %llu\n", (unsigned long long)total);
+    tz_reanalyze_destroy(ra);
+    tzo_search_destroy(s);
+    return 0;
+}

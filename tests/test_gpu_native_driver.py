@@ -191,3 +191,38 @@ def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
     replays = open(os.path.join(d, "replays.txt"), "rb").read()
     assert targets.count(b"\n") == int(fields["targets"]) and replays.count(b"\n") == int(fields["replays"])
     _check_lines(oracle, n, targets, replays, "gumbel")
+
+
+@pytest.mark.parametrize("kind,sims,k,exploration,agent,n", [(0, 24, 64, 1, 2, 4), (1, 16, 4, 0, 2, 4), (1, 48, 8, 1, 1, 5), (2, 0, 64, 0, 1, 4)])
+def test_native_drivers_write_the_same_bytes_over_the_gpu_engine_and_over_the_oracle(tmp_path, kind, sims, k, exploration, agent, n):
+    """The strongest statement about the whole loop: csrc/tz_host.cpp driving the HIP engine and the very same driver
+    code driving the CPU oracle (tests/host_over_oracle.cpp), same seed — every target line, every replay line, every
+    reanalyze target must be identical bytes.  That holds only if every search result the driver ever looked at
+    (visit counts, evaluations, policies, UBE targets, terminal results) was bit-identical, move after move."""
+    from host_oracle_util import build, run
+
+    A = require_gpu()
+    from takzero_amd import reanalyze as RA
+    from takzero_amd import selfplay as SP
+
+    B, moves, seed = 24, 50, 9
+    want = run(build(tmp_path, sanitize=False), tmp_path / "cpu", n, 4, agent, B, kind, sims, k, exploration, moves, seed)
+    mcts = A.BatchedMCTS(B, n, 4, agent_kind=agent, node_capacity=1 << 15)
+    sp = SP.NativeSelfPlay(mcts, sims, seed=seed, shard=0, search={0: "puct", 1: "gumbel", 2: "random"}[kind], sampled_actions=k,
+                           exploration=bool(exploration))
+    got = {"targets": b"", "replays": b"", "exploration": b""}
+    for _ in range(moves):
+        sp.play_move()
+        got["targets"] += sp.take_text(0)
+        got["replays"] += sp.take_text(1)
+        got["exploration"] += sp.take_text(2)
+    for part in ("replays", "exploration", "targets"):
+        assert got[part] == want[part], part
+    rpath = tmp_path / "gpu.replays"
+    rpath.write_bytes(got["replays"])
+    ra = RA.NativeReanalyze(mcts, sims if kind == 1 else 32, seed=seed + 1, search="gumbel" if kind == 1 else "puct", sampled_actions=k)
+    assert ra.feed(rpath) == want["positions"]
+    if want["positions"] >= B:
+        ra.iterate()
+        ra.iterate()
+    assert ra.take_text() == want["reanalyze"]
