@@ -285,6 +285,11 @@ int tzo_search_restart_terminal(tzo_search* s, const int32_t* choice, int8_t* te
 int tzo_search_gumbel_sh(tzo_search* s, const float* betas, int sampled_actions, int search_budget,
                          const float* gumbel, int amax, uint16_t* selected_out) {
     size_t B = s->mcts->batch();
+    {   // batched.rs:216-220 asserts that the budget is a whole number of halving rounds
+        int lg = 0;
+        while ((1 << (lg + 1)) <= sampled_actions) lg++;
+        if (sampled_actions <= 0 || lg == 0 || search_budget % (sampled_actions * lg)) return -1;  // ilog2(k) * k
+    }
     std::vector<float> b(betas, betas + B);
     std::vector<std::vector<float>> g(B);
     for (size_t i = 0; i < B; i++) g[i].assign(gumbel + i * amax, gumbel + (i + 1) * amax);

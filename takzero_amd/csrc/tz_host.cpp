@@ -365,7 +365,6 @@ int tz_selfplay_create(TZ_SEARCH_T* search, int sims_per_move, uint64_t seed, in
     sp->sims = sims_per_move;
     sp->kind = search_kind;
     sp->k = sampled_actions > 0 ? sampled_actions : 64;
-    if (search_kind == 1 && (sp->k & (sp->k - 1))) return tz_fail(TZ_EINVAL, "tz_selfplay_create: sampled_actions must be a power of two");
     const int B = sp->B;
     sp->betas.assign(B, 0.0f);
     if (exploration)
