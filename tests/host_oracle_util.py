@@ -7,23 +7,29 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build(out_dir, sanitize):
-    exe = os.path.join(str(out_dir), "host_over_oracle" + ("_san" if sanitize else ""))
+def build(out_dir, sanitize, with_net=False):
+    exe = os.path.join(str(out_dir), "host_over_oracle" + ("_san" if sanitize else "") + ("_net" if with_net else ""))
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "takzero_amd", "csrc"),
            os.path.join(ROOT, "tests", "host_over_oracle.cpp"), os.path.join(ROOT, "oracle", "capi.cpp"),
            os.path.join(ROOT, "takzero_amd", "csrc", "tz_text.cpp"), "-lpthread", "-o", exe]
     if sanitize:
         cmd[4:4] = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    if with_net:   # the oracle search's Agent = the HIP network through tz_net_eval; tz_text.cpp then comes from the library
+        lib = os.path.join(ROOT, "takzero_amd")
+        cmd.remove(os.path.join(ROOT, "takzero_amd", "csrc", "tz_text.cpp"))
+        cmd[4:4] = ["-DTZ_HARNESS_WITH_NET"]
+        cmd += ["-L" + lib, "-ltakzero_hip", "-Wl,-rpath," + lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("cannot build the harness here: " + r.stderr[-400:])
     return exe
 
 
-def run(exe, prefix, n, half_komi, agent, batch, kind, sims, k, exploration, moves, seed):
+def run(exe, prefix, n, half_komi, agent, batch, kind, sims, k, exploration, moves, seed, net_args=()):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
-    r = subprocess.run([exe] + [str(x) for x in (n, half_komi, agent, batch, kind, sims, k, exploration, moves, seed)] + [str(prefix)],
+    r = subprocess.run([exe] + [str(x) for x in (n, half_komi, agent, batch, kind, sims, k, exploration, moves, seed)] + [str(prefix)]
+                       + [str(x) for x in net_args],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-300:], r.stderr[-2000:])
     out = {}

@@ -3,6 +3,8 @@
 // driver code, same seed => the text it produces over the oracle must equal, byte for byte, what it produces over the
 // GPU engine (tests/test_gpu_native_driver.py); and being pure CPU code it also runs under ASan / UBSan.
 //   host_over_oracle <n> <half_komi> <agent 1|2> <batch> <kind 0|1|2> <sims> <k> <exploration> <moves> <seed> <out prefix>
+// With -DTZ_HARNESS_WITH_NET (GPU box only, linked against libtakzero_hip.so) agent 0 = the HIP network called through
+// tz_net_eval as the oracle search's Agent; four more arguments: <model.tzw> <arch> <blocks> <precision>.
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -48,13 +50,37 @@ static void dump(const std::string& path, const std::string& text) {
     fclose(f);
 }
 
+#ifdef TZ_HARNESS_WITH_NET
+static void net_agent(void* user, int n_envs, const tz_state* states, const uint16_t* legal_idx, const int32_t* legal_count, int amax,
+                      float* logits, float* value, float* variance) {
+    if (tz_net_eval(static_cast<tz_net*>(user), n_envs, states, legal_idx, legal_count, amax, logits, value, variance)) {
+        fprintf(stderr, "tz_net_eval: %s\n", tz_last_error());
+        abort();
+    }
+}
+#endif
+
 int main(int argc, char** argv) {
-    if (argc != 12) return 2;
+    if (argc != 12 && argc != 16) return 2;
     const int n = atoi(argv[1]), hk = atoi(argv[2]), agent = atoi(argv[3]), B = atoi(argv[4]), kind = atoi(argv[5]), sims = atoi(argv[6]),
               k = atoi(argv[7]), exploration = atoi(argv[8]), moves = atoi(argv[9]);
     const uint64_t seed = strtoull(argv[10], nullptr, 10);
     const std::string prefix = argv[11];
-    tzo_search* s = tzo_search_create(agent, nullptr, nullptr, B, n, hk);
+    tzo_agent_fn fn = nullptr;
+    void* user = nullptr;
+#ifdef TZ_HARNESS_WITH_NET
+    if (agent == 0) {
+        if (argc != 16) return 2;
+        tz_net* net = nullptr;
+        if (tz_net_create(n, atoi(argv[13]), 0, atoi(argv[15]), atoi(argv[14]), &net) || tz_net_load_weights(net, argv[12])) {
+            fprintf(stderr, "net: %s\n", tz_last_error());
+            return 8;
+        }
+        fn = net_agent;
+        user = net;
+    }
+#endif
+    tzo_search* s = tzo_search_create(agent, fn, user, B, n, hk);
     tz_selfplay* sp = nullptr;
     if (tz_selfplay_create(s, sims, seed, 0, kind, k, exploration, &sp)) return 3;
     std::string targets, replays, expl;

@@ -226,3 +226,33 @@ def test_native_drivers_write_the_same_bytes_over_the_gpu_engine_and_over_the_or
         ra.iterate()
         ra.iterate()
     assert ra.take_text() == want["reanalyze"]
+
+
+@pytest.mark.parametrize("kind,sims,k,prec", [(0, 24, 64, 2), (1, 16, 4, 0)])
+def test_whole_loop_bytes_with_the_real_network(tmp_path, kind, sims, k, prec):
+    """The same byte-for-byte statement with the network in the loop: the HIP engine (fused trunk kernel, leaf batches
+    compacted on the device) against the oracle search whose Agent is that HIP network called through tz_net_eval."""
+    from host_oracle_util import build, run
+
+    A = require_gpu()
+    from takzero_amd import selfplay as SP
+    from takzero_amd import weights as W
+
+    n, blocks, B, moves, seed = 4, 1, 16, 40, 3
+    w = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=17)
+    model = tmp_path / "model.tzw"
+    W.save_tzw(model, w)
+    want = run(build(tmp_path, sanitize=False, with_net=True), tmp_path / "cpu", n, 4, 0, B, kind, sims, k, 1, moves, seed,
+               net_args=(model, A.ARCH_TEST, blocks, prec))
+    net = A.Net(arch=A.ARCH_TEST, n=n, precision=prec, blocks=blocks).load_tensors(w)
+    mcts = A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 14)
+    sp = SP.NativeSelfPlay(mcts, sims, seed=seed, shard=0, search="puct" if kind == 0 else "gumbel", sampled_actions=k, exploration=True)
+    got = {"targets": b"", "replays": b"", "exploration": b""}
+    for _ in range(moves):
+        sp.play_move()
+        got["targets"] += sp.take_text(0)
+        got["replays"] += sp.take_text(1)
+        got["exploration"] += sp.take_text(2)
+    assert got["replays"] and got["targets"]
+    for part in ("replays", "exploration", "targets"):
+        assert got[part] == want[part], part
