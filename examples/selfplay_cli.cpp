@@ -93,8 +93,15 @@ int main(int argc, char** argv) {
     unsigned long long played = 0, targets = 0, replays = 0, simulations = 0, evals = 0;
     CHECK(tz_selfplay_counters(sp, (uint64_t*)&played, (uint64_t*)&targets, (uint64_t*)&replays));
     CHECK(tz_search_counters(mcts, (uint64_t*)&simulations, (uint64_t*)&evals));
-    printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f\n", played,
-           targets, replays, simulations, evals, reload.reloads, seconds, (double)simulations / seconds);
+    long rss_kb = 0;   // resident set of this process (host memory of the driver: move history, text buffers)
+    if (FILE* f = fopen("/proc/self/status", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "VmRSS: %ld kB", &rss_kb) == 1) break;
+        fclose(f);
+    }
+    printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f rss_mb %ld\n",
+           played, targets, replays, simulations, evals, reload.reloads, seconds, (double)simulations / seconds, rss_kb / 1024);
     tz_selfplay_destroy(sp);
     tz_search_destroy(mcts);
     tz_net_destroy(net);
