@@ -113,6 +113,16 @@ def main():
                     help="16-bit storage type of the MFMA path (same kernels, same rate; f16 is within 1e-3 of fp32)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as plain `python bench.py --gpus N`: run the N ranks as a child torch.distributed.run job (nothing in
+        # this process has touched the GPU yet) and hand its exit code back
+        import subprocess
+
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -52,3 +52,15 @@ def test_two_rank_launch_as_the_driver_does_it():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     # whole-job aggregate: 2 ranks x 128 games x 33 simulate calls per move x 2 timed moves
     assert abs(out["value"] * out["ms_per_step"] * 2 / 1000.0 - 2 * 128 * 33 * 2) < 0.02 * 2 * 128 * 33 * 2
+
+
+@pytest.mark.gpu
+def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
+    env = dict(os.environ, TZ_BENCH_BACKEND="gloo", TZ_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--games", "128",
+                        "--sims", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
