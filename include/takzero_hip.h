@@ -261,6 +261,14 @@ int tz_reanalyze_take_text(tz_reanalyze* ra, char* out, uint64_t cap, uint64_t* 
 int tz_reanalyze_run(tz_reanalyze* ra, const char* directory, int iterations, int min_positions, const char* suffix,
                      int (*reload)(void*), void* reload_user, double wait_limit_s);
 
+/* ---------- the other consumers of the search, native host code ----------
+ * evaluation::compete (evaluation/src/main.rs:224-319): result_out[3] = wins, losses, draws for White. */
+int tz_compete(tz_search* white, tz_search* black, const tz_state* games, float white_beta, float black_beta, uint64_t seed,
+               int sampled_actions, int search_budget, int max_moves, int32_t* result_out);
+/* puzzle benchmark (puzzle/src/main.rs:168-269): result_out[3] = attempted, solved, proven. */
+int tz_puzzle_benchmark(tz_search* search, const tz_state* puzzles, const uint16_t* solutions, int count, int win, uint64_t seed,
+                        int sampled_actions, int search_budget, int32_t* result_out);
+
 /* ---------- Target lines in bulk (impl Display / FromStr for Target, target.rs:56-73, 99-143) ----------
  * "{tps};{value};{ube};{move}:{p},...\n" with Rust's `Display for f32`.  moves / policy are [count][amax]. */
 int tz_format_targets(int n, int count, const tz_state* states, const uint16_t* moves, const float* policy,

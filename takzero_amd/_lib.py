@@ -35,7 +35,7 @@ SYMBOLS = [
     "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
     "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
     "tz_selfplay_run", "tz_reanalyze_create", "tz_reanalyze_destroy", "tz_reanalyze_feed", "tz_reanalyze_iterate",
-    "tz_reanalyze_take_text", "tz_reanalyze_run",
+    "tz_reanalyze_take_text", "tz_reanalyze_run", "tz_compete", "tz_puzzle_benchmark",
 ]
 
 _lib = None
@@ -119,6 +119,8 @@ def load():
     lib.tz_reanalyze_iterate.argtypes = [vp]
     lib.tz_reanalyze_take_text.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.tz_reanalyze_run.argtypes = [vp, C.c_char_p, ci, ci, C.c_char_p, vp, vp, C.c_double]
+    lib.tz_compete.argtypes = [vp, vp, vp, cf, cf, C.c_uint64, ci, ci, ci, vp]
+    lib.tz_puzzle_benchmark.argtypes = [vp, vp, vp, ci, ci, C.c_uint64, ci, ci, vp]
     lib.tz_trainer_create.argtypes = [ci, ci, ci, ci, ci, cf, C.POINTER(vp)]
     lib.tz_trainer_destroy.argtypes = [vp]
     lib.tz_trainer_tensor_count.argtypes = [vp]

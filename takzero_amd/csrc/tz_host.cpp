@@ -868,3 +868,142 @@ int tz_reanalyze_run(tz_reanalyze* ra, const char* directory, int iterations, in
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// The two other consumers of the search ABI, natively.
+extern "C" {
+
+// evaluation::compete (evaluation/src/main.rs:224-319): two searches (one per side, usually two networks) over the
+// same `games`; the side to move picks its move by Gumbel sequential halving and BOTH trees are stepped with it.
+// result_out[3] = wins, losses, draws from White's point of view.
+int tz_compete(TZ_SEARCH_T* white, TZ_SEARCH_T* black, const tz_state* games, float white_beta, float black_beta, uint64_t seed,
+               int sampled_actions, int search_budget, int max_moves, int32_t* result_out) {
+    if (!white || !black || !games || !result_out) return tz_fail(TZ_EINVAL, "tz_compete: null argument");
+    int B = 0, Bb = 0, n = 0, nb = 0, hk = 0, amax = 0;
+    int rc = TZS(shape)(white, &B, &n, &hk, &amax);
+    if (rc) return rc;
+    if ((rc = TZS(shape)(black, &Bb, &nb, nullptr, nullptr))) return rc;
+    if (B != Bb || n != nb) return tz_fail(TZ_EINVAL, "tz_compete: the two searches differ in batch or board size");
+    std::seed_seq seq{(uint32_t)seed, (uint32_t)(seed >> 32), 0xc0de7e57u};
+    std::mt19937_64 rng(seq);
+    std::vector<int32_t> idx(B), choice(B);
+    for (int g = 0; g < B; g++) idx[g] = g;
+    if ((rc = TZS(set_positions)(white, B, idx.data(), games))) return rc;   // BatchedMCTS::from_envs(games) x2 (:240-241)
+    if ((rc = TZS(set_positions)(black, B, idx.data(), games))) return rc;
+    std::vector<float> beta_w(B, white_beta), beta_b(B, black_beta), gumbel((size_t)B * amax);
+    std::vector<uint16_t> top(B);
+    std::vector<int8_t> term(B);
+    std::vector<char> done(B, 0);
+    std::vector<tz_state> cur_states(B), moved;
+    std::vector<int32_t> didx;
+    int wins = 0, losses = 0, draws = 0;
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    std::uniform_int_distribution<int> open(0, 15);
+    for (int mv = 0; mv < max_moves; mv++) {
+        for (int side = 0; side < 2; side++) {
+            bool all = true;
+            for (int g = 0; g < B; g++) all = all && done[g];
+            if (all) goto finished;
+            {
+                const bool is_white = side == 0;
+                TZ_SEARCH_T* cur = is_white ? white : black;
+                TZ_SEARCH_T* oth = is_white ? black : white;
+                for (auto& x : gumbel) {
+                    double u = uni(rng);
+                    if (u <= 0.0) u = 1e-300;
+                    x = (float)(-std::log(-std::log(u)));
+                }
+                if ((rc = TZS(gumbel_sh)(cur, (is_white ? beta_w : beta_b).data(), sampled_actions, search_budget, gumbel.data(), amax,
+                                        top.data())))
+                    return rc;                                               // :257-273
+                if ((rc = TZS(step)(cur, top.data()))) return rc;            // :276-277
+                if ((rc = TZS(step)(oth, top.data()))) return rc;
+                for (int g = 0; g < B; g++) choice[g] = open(rng);
+                if ((rc = TZS(restart_terminal)(cur, choice.data(), term.data()))) return rc;  // :280-288
+                bool any_done = false;
+                for (int g = 0; g < B; g++) {
+                    if (term[g] != TZ_TERMINAL_NONE && !done[g]) {
+                        // seen after the move: a Loss for the side to move is a win for the mover (:306-313)
+                        if (term[g] == TZ_TERMINAL_DRAW) draws++;
+                        else if ((term[g] == TZ_TERMINAL_LOSS) == is_white) wins++;
+                        else losses++;
+                    }
+                    if (term[g] != TZ_TERMINAL_NONE) done[g] = 1;
+                    any_done = any_done || done[g];
+                }
+                if (any_done) {  // the other side's nodes and envs of finished games are reset too (:290-299)
+                    if ((rc = TZS(get_positions)(cur, cur_states.data()))) return rc;
+                    didx.clear();
+                    moved.clear();
+                    for (int g = 0; g < B; g++)
+                        if (done[g]) {
+                            didx.push_back(g);
+                            moved.push_back(cur_states[g]);
+                        }
+                    if ((rc = TZS(set_positions)(oth, (int)didx.size(), didx.data(), moved.data()))) return rc;
+                }
+            }
+        }
+    }
+finished:
+    result_out[0] = wins;
+    result_out[1] = losses;
+    result_out[2] = draws;
+    return TZ_OK;
+}
+
+// puzzle `benchmark` (puzzle/src/main.rs:168-269): `count` positions solved in batches with Gumbel sequential halving at
+// beta 0; solved = select_best_action equals the solution; proven = root solved to a win (win != 0) or all children but
+// one solved as wins.  result_out[3] = attempted, solved, proven.
+int tz_puzzle_benchmark(TZ_SEARCH_T* search, const tz_state* puzzles, const uint16_t* solutions, int count, int win, uint64_t seed,
+                        int sampled_actions, int search_budget, int32_t* result_out) {
+    if (!search || !puzzles || !solutions || !result_out || count < 0) return tz_fail(TZ_EINVAL, "tz_puzzle_benchmark: bad argument");
+    int B = 0, n = 0, hk = 0, amax = 0;
+    int rc = TZS(shape)(search, &B, &n, &hk, &amax);
+    if (rc) return rc;
+    std::seed_seq seq{(uint32_t)seed, (uint32_t)(seed >> 32), 0x9a221eu};
+    std::mt19937_64 rng(seq);
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    std::vector<int32_t> idx(B);
+    for (int g = 0; g < B; g++) idx[g] = g;
+    std::vector<tz_state> states(B);
+    std::vector<float> zero_beta(B, 0.0f), gumbel((size_t)B * amax);
+    std::vector<uint16_t> selected(B), ignored(B);
+    std::vector<tz_root_info> info(B);
+    int attempted = 0, solved = 0, proven = 0;
+    for (int lo = 0; lo < count; lo += B) {
+        const int kk = std::min(B, count - lo);
+        if ((rc = TZS(get_positions)(search, states.data()))) return rc;  // a short last batch keeps the previous tail (:198-204)
+        for (int g = 0; g < kk; g++) states[g] = puzzles[lo + g];
+        if ((rc = TZS(set_positions)(search, B, idx.data(), states.data()))) return rc;  // every node reset (:195-197)
+        for (auto& x : gumbel) {
+            double u = uni(rng);
+            if (u <= 0.0) u = 1e-300;
+            x = (float)(-std::log(-std::log(u)));
+        }
+        if ((rc = TZS(gumbel_sh)(search, zero_beta.data(), sampled_actions, search_budget, gumbel.data(), amax, ignored.data()))) return rc;
+        if ((rc = TZS(select_best_actions)(search, selected.data()))) return rc;         // :215
+        if ((rc = TZS(root_info)(search, info.data()))) return rc;
+        attempted += kk;
+        for (int g = 0; g < kk; g++) solved += selected[g] == solutions[lo + g];
+        if (win) {
+            for (int g = 0; g < kk; g++) proven += info[g].eval_tag == TZ_EVAL_WIN;      // :237-243
+        } else {
+            int w = 1;
+            for (int g = 0; g < B; g++) w = std::max(w, (int)info[g].n_children);
+            std::vector<uint8_t> tag((size_t)B * w);
+            if ((rc = TZS(root_children)(search, w, nullptr, nullptr, tag.data(), nullptr, nullptr, nullptr, nullptr))) return rc;
+            for (int g = 0; g < kk; g++) {                                               // :244-258
+                int wins = 0;
+                for (int i = 0; i < (int)info[g].n_children; i++) wins += tag[(size_t)g * w + i] == TZ_EVAL_WIN;
+                proven += wins == (int)info[g].n_children - 1;
+            }
+        }
+    }
+    result_out[0] = attempted;
+    result_out[1] = solved;
+    result_out[2] = proven;
+    return TZ_OK;
+}
+
+}  // extern "C"

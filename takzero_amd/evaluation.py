@@ -58,3 +58,17 @@ def compete(white_mcts, black_mcts, games, white_beta, black_beta, rng, sampled_
                 else:
                     ev.losses += 1
     return ev
+
+
+def compete_native(white_mcts, black_mcts, games, white_beta, black_beta, seed=0, sampled_actions=SAMPLED_ACTIONS,
+                   search_budget=SEARCH_BUDGET, max_moves=MAX_MOVES):
+    """The same match played by native code (tz_compete, csrc/tz_host.cpp); draws come from a generator seeded there."""
+    from . import _lib
+
+    st = api._states(games)
+    out = np.zeros(3, np.int32)
+    _lib.check(_lib.load().tz_compete(white_mcts.h, black_mcts.h, st.ctypes.data, white_beta, black_beta, seed, sampled_actions,
+                                      search_budget, max_moves, out.ctypes.data))
+    ev = Evaluation()
+    ev.wins, ev.losses, ev.draws = (int(x) for x in out)
+    return ev

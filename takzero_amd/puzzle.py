@@ -101,3 +101,15 @@ def run(mcts, db_path, sampled_actions=64, search_budget=768, log=print):
             if log:
                 log("%s %d: %r %s" % (kind, depth, res, res.solve_rate()))
     return out
+
+
+def benchmark_native(mcts, puzzles, solutions, win, sampled_actions, search_budget, seed=SEED):
+    """`benchmark` in native code (tz_puzzle_benchmark, csrc/tz_host.cpp)."""
+    from . import _lib
+
+    st = api._states(puzzles)
+    sol = np.ascontiguousarray(solutions, np.uint16)
+    out = np.zeros(3, np.int32)
+    _lib.check(_lib.load().tz_puzzle_benchmark(mcts.h, st.ctypes.data, sol.ctypes.data, len(st), 1 if win else 0, seed,
+                                               sampled_actions, search_budget, out.ctypes.data))
+    return PuzzleResult(int(out[0]), int(out[1]), int(out[2]))

@@ -33,7 +33,7 @@ def run(exe, prefix, n, half_komi, agent, batch, kind, sims, k, exploration, mov
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-300:], r.stderr[-2000:])
     out = {}
-    for part in ("targets", "replays", "exploration", "reanalyze"):
+    for part in ("targets", "replays", "exploration", "reanalyze", "consumers"):
         with open("%s.%s" % (prefix, part), "rb") as f:
             out[part] = f.read()
     out["positions"] = int(r.stdout.split()[1])

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "takzero_hip.h"
 
@@ -42,6 +43,8 @@ int tzo_search_gumbel_sh(tzo_search* s, const float* betas, int sampled_actions,
 // the two constructors take the search handle: give this build's versions names of their own
 #define tz_selfplay_create tzh_selfplay_create
 #define tz_reanalyze_create tzh_reanalyze_create
+#define tz_compete tzh_compete
+#define tz_puzzle_benchmark tzh_puzzle_benchmark
 #include "../takzero_amd/csrc/tz_host.cpp"
 
 static void dump(const std::string& path, const std::string& text) {
@@ -118,6 +121,42 @@ int main(int argc, char** argv) {
     dump(prefix + ".reanalyze", re);
     printf("positions %llu\n", (unsigned long long)total);
     tz_reanalyze_destroy(ra);
+    // evaluation::compete and the puzzle benchmark on the 16 openings (game g starts from opening g % 16)
+    {
+        tzo_search* other = tzo_search_create(agent == 1 ? 2 : 1, nullptr, nullptr, B, n, hk);  // the other built-in agent plays Black
+        std::vector<int32_t> choice(B);
+        for (int g = 0; g < B; g++) choice[g] = g % 16;
+        tzo_search_new_openings(s, choice.data());
+        std::vector<tz_state> games(B);
+        tzo_search_get_positions(s, games.data());
+        int32_t res[3] = {0, 0, 0}, pz[6] = {0, 0, 0, 0, 0, 0};
+        const int budget = k >= 2 ? k * (31 - __builtin_clz((unsigned)k)) * 2 : 8;
+        if (tz_compete(s, other, games.data(), 0.0f, 0.25f, seed + 2, k >= 2 ? k : 4, k >= 2 ? budget : 16, 6, res)) {
+            fprintf(stderr, "compete: %s\n", tz_last_error());
+            return 9;
+        }
+        std::vector<tz_state> puzzles(B + B / 2);
+        std::vector<uint16_t> solutions(B + B / 2, 0);
+        for (size_t i = 0; i < puzzles.size(); i++) puzzles[i] = games[i % B];
+        if (tz_puzzle_benchmark(s, puzzles.data(), solutions.data(), (int)puzzles.size(), 1, seed + 3, k >= 2 ? k : 4, k >= 2 ? budget : 16, pz) ||
+            tz_puzzle_benchmark(s, puzzles.data(), solutions.data(), (int)puzzles.size(), 0, seed + 3, k >= 2 ? k : 4, k >= 2 ? budget : 16, pz + 3)) {
+            fprintf(stderr, "puzzle: %s\n", tz_last_error());
+            return 10;
+        }
+        std::vector<tz_state> fin(B);
+        tzo_search_get_positions(other, fin.data());
+        std::string out = std::to_string(res[0]) + " " + std::to_string(res[1]) + " " + std::to_string(res[2]);
+        for (int i = 0; i < 6; i++) out += " " + std::to_string(pz[i]);
+        out += "\n";
+        char buf[256];
+        for (int g = 0; g < B; g++) {
+            tz_state_to_tps(&fin[g], buf, sizeof buf);
+            out += buf;
+            out += "\n";
+        }
+        dump(prefix + ".consumers", out);
+        tzo_search_destroy(other);
+    }
     tzo_search_destroy(s);
     return 0;
 }

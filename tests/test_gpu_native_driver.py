@@ -226,6 +226,24 @@ def test_native_drivers_write_the_same_bytes_over_the_gpu_engine_and_over_the_or
         ra.iterate()
         ra.iterate()
     assert ra.take_text() == want["reanalyze"]
+    # evaluation::compete and the puzzle benchmark, natively, on the 16 openings: same counts, same final positions
+    from takzero_amd import evaluation as E
+    from takzero_amd import puzzle as P
+
+    other = A.BatchedMCTS(B, n, 4, agent_kind=2 if agent == 1 else 1, node_capacity=1 << 15)
+    mcts.new_openings(np.arange(B) % 16)
+    games = mcts.get_positions()
+    kk = k if k >= 2 else 4
+    budget = k * (k.bit_length() - 1) * 2 if k >= 2 else 16
+    ev = E.compete_native(mcts, other, games, 0.0, 0.25, seed=seed + 2, sampled_actions=kk, search_budget=budget, max_moves=6)
+    puzzles = np.concatenate([games, games[:B // 2]])
+    solutions = np.zeros(len(puzzles), np.uint16)
+    pw = P.benchmark_native(mcts, puzzles, solutions, True, kk, budget, seed=seed + 3)
+    pa = P.benchmark_native(mcts, puzzles, solutions, False, kk, budget, seed=seed + 3)
+    lines = ["%d %d %d %d %d %d %d %d %d" % (ev.wins, ev.losses, ev.draws, pw.attempted, pw.solved, pw.proven, pa.attempted, pa.solved,
+                                              pa.proven)]
+    lines += [A.state_to_tps(st) for st in other.get_positions()]
+    assert ("\n".join(lines) + "\n").encode() == want["consumers"]
 
 
 @pytest.mark.parametrize("kind,sims,k,prec", [(0, 24, 64, 2), (1, 16, 4, 0)])
