@@ -18,7 +18,7 @@
 struct Reload {
     tz_net* net;
     std::string path;
-    long long stamp_s = -1, stamp_ns = -1, size = -1;
+    long long stamp_s = -1, stamp_ns = -1, size = -1, inode = -1;
     int reloads = 0;
 };
 
@@ -26,7 +26,8 @@ static int reload_model(void* user) {
     Reload* r = static_cast<Reload*>(user);
     struct stat st;
     if (stat(r->path.c_str(), &st) != 0) return 0;  // no new model yet: keep playing with the current one
-    if (st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size) return 0;
+    if (st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size && (long long)st.st_ino == r->inode)
+        return 0;
     if (tz_net_load_weights(r->net, r->path.c_str()) != 0) {
         fprintf(stderr, "Cannot load model: %s, not retrying.\n", tz_last_error());  // the old weights stay active
         return 0;
@@ -34,6 +35,7 @@ static int reload_model(void* user) {
     r->stamp_s = st.st_mtim.tv_sec;
     r->stamp_ns = st.st_mtim.tv_nsec;
     r->size = st.st_size;
+    r->inode = (long long)st.st_ino;
     r->reloads++;
     return 0;
 }

@@ -36,7 +36,7 @@ def read_buffer_lengths(directory):
 
 class ModelWatcher:
     """Net::load(directory/model_latest.ot) before every search.  The reference re-reads the file every time;
-    we re-read it only when its (mtime, size) changed, which gives the same network."""
+    we re-read it only when its (mtime, size, inode) changed, which gives the same network."""
 
     def __init__(self, net, directory, name="model_latest.ot"):
         self.net, self.path, self.stamp, self.reloads = net, os.path.join(directory, name), None, 0
@@ -44,7 +44,7 @@ class ModelWatcher:
     def refresh(self):
         """True if a (new) model is loaded; raises OSError if the file is missing (caller retries)."""
         st = os.stat(self.path)
-        stamp = (st.st_mtime_ns, st.st_size)
+        stamp = (st.st_mtime_ns, st.st_size, st.st_ino)   # writers rename a fresh file into place: the inode changes too
         if stamp != self.stamp:
             self.net.load(self.path)
             self.stamp = stamp
@@ -72,7 +72,7 @@ class BroadcastModelWatcher(ModelWatcher):
         if self.rank == 0:
             try:
                 st = os.stat(self.path)
-                stamp = (st.st_mtime_ns, st.st_size)
+                stamp = (st.st_mtime_ns, st.st_size, st.st_ino)   # writers rename a fresh file into place: the inode changes too
                 if stamp != self.stamp:
                     tensors = ot.load_ot(self.path) if self.path.endswith(".ot") else None
                     if tensors is None:
