@@ -583,6 +583,33 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                     } else if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * KSTEP);
                     else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
                 }
+                if constexpr (OPT & 128) {  // A/B: pin the issue order of a k-step to 2 MFMA : 1 ds_read, row tile by row tile
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if constexpr (OPT & 512) {  // A/B: two row tiles at a time: 4 MFMA : 2 ds_read
+#pragma unroll
+                    for (int rt = 0; rt + 1 < RT; rt += 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * RN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    if (RT & 1) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if constexpr (OPT & 256) {  // A/B: the same with each ds_read one row tile behind the MFMAs that free its register
+                    __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+#pragma unroll
+                    for (int rt = 1; rt < RT; rt++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
         // ---- layer epilogue.  A wave's 32 output channels are exactly one plane of the LDS image, and it is the
@@ -703,6 +730,14 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, int lr, int
                 for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
                 if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
                 else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+            }
+            // pin the issue order of the k-step: the MFMAs of a row tile, then the ds_read that refills its fragment
+            // (measured on the tower twin of this loop, `tools/tower_bench.py 0 128`: 3.375 -> 3.347 ms; the scheduler's
+            // own order, a one-tile lag of the reads, and 4 MFMA : 2 reads are all slower)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
     }
@@ -2096,6 +2131,9 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 48: r = launch_tower<5, 48>(a, positions, net->stream); break;
                 case 64: r = launch_tower<5, 64>(a, positions, net->stream); break;
                 case 112: r = launch_tower<5, 112>(a, positions, net->stream); break;
+                case 128: r = launch_tower<5, 128>(a, positions, net->stream); break;
+                case 256: r = launch_tower<5, 256>(a, positions, net->stream); break;
+                case 512: r = launch_tower<5, 512>(a, positions, net->stream); break;
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
