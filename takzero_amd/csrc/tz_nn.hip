@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 #pragma unroll
                     for (int j = 0; j < RN; j++) bq[(kc + PD) & 3][j] = wload(layer + 1, 0, kc + PD - 8, j);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(OPT & 2048)) __builtin_amdgcn_sched_barrier(0);
                 if (kc == 7) {
                     int lr_t = lr;
                     asm volatile("" : "+v"(lr_t));
@@ -588,6 +588,22 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                     for (int rt = 0; rt < RT; rt++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if constexpr (OPT & 1024) {  // A/B: 2 MFMA : 1 ds_read : up to 3 VALU (address arithmetic at tap boundaries spread out)
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    }
+                }
+                if constexpr (OPT & 2048) {  // A/B: no hard barrier after the weight loads; they are placed a third and two thirds in
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (rt == RT / 3 || rt == 2 * RT / 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
                 if constexpr (OPT & 512) {  // A/B: two row tiles at a time: 4 MFMA : 2 ds_read
@@ -2134,6 +2150,8 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 128: r = launch_tower<5, 128>(a, positions, net->stream); break;
                 case 256: r = launch_tower<5, 256>(a, positions, net->stream); break;
                 case 512: r = launch_tower<5, 512>(a, positions, net->stream); break;
+                case 1024: r = launch_tower<5, 1024>(a, positions, net->stream); break;
+                case 2048: r = launch_tower<5, 2048>(a, positions, net->stream); break;
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
