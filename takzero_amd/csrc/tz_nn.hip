@@ -502,6 +502,19 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
             if (row < LROWS) *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v[i];
         }
     }
+    // OPT 4096 (A/B): the per-tap fragment base addresses of a lane (13 values per tap, the same in every layer) are
+    // computed once into LDS behind the image, so a tap boundary costs 13 ds_read_b32 instead of ~130 VALU instructions
+    int* tap_table = reinterpret_cast<int*>(lds + 8 * PLANE);  // [TAPS][RT][64 lanes]
+    if constexpr (OPT & 4096) {
+        if (wave == 0) {
+            for (int tap = 0; tap < TAPS; tap++) {
+                int tb[RT];
+                tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = tb[rt];
+            }
+        }
+    }
     // address of this lane's 4 output channels of pixel row (rt*16 + lr) in the LDS image: its wave's 32
     // channels are plane `wave`; + rt * 1024
     int obase[RN];
@@ -539,7 +552,10 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
             if (wave >= 4) __builtin_amdgcn_s_sleep(10);
         }
         int abase[RT];
-        {
+        if constexpr (OPT & 4096) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[rt * 64 + lane];
+        } else {
             int lr_t = lr;
             asm volatile("" : "+v"(lr_t));
             tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr_t, q, ROWS, ZROW, abase);
@@ -563,9 +579,15 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 }
                 if constexpr (!(OPT & 2048)) __builtin_amdgcn_sched_barrier(0);
                 if (kc == 7) {
-                    int lr_t = lr;
-                    asm volatile("" : "+v"(lr_t));
-                    tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
+                    if constexpr (OPT & 4096) {
+                        const int nt = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+                        for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(nt * RT + rt) * 64 + lane];
+                    } else {
+                        int lr_t = lr;
+                        asm volatile("" : "+v"(lr_t));
+                        tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
+                    }
                 }
                 if (kc == 4) {
 #pragma unroll
@@ -698,10 +720,13 @@ struct NetArgs {
 
 // 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
 // weight fragments two k-steps ahead through a 4-slot ring (see tower_mfma_kernel)
+// tap_table[tap][rt][lane]: the lane's fragment base address for row tile rt under tap `tap` (tap_bases_rc, computed once
+// per kernel into LDS: a tap boundary then costs RT ds_read_b32 instead of ~10 VALU instructions per row tile —
+// measured on the tower twin, `tools/tower_bench.py 128 4224`: 3.376 -> 3.065 ms)
 template <int NB, int RT, int RNX, int ROWS, int ZROW, int PLANE, typename ET, typename WL>
-__device__ __forceinline__ void k_loop_256(const unsigned char* lds, int lr, int q, f32x4 (&acc)[RT][RNX], WL wl) {
+__device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&acc)[RT][RNX], WL wl) {
     typedef typename Elem<ET>::x8 ex8;
-    constexpr int TAPS = 9, LAYOUT = 1;
+    constexpr int TAPS = 9;
     ex8 bq[4][RNX];
 #pragma unroll
     for (int j = 0; j < RNX; j++) {
@@ -709,11 +734,8 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, int lr, int
         bq[1][j] = wl(0, 1, j);
     }
     int abase[RT];
-    {
-        int lr_t = lr;
-        asm volatile("" : "+v"(lr_t));
-        tap_bases_rc<NB, RT, TAPS, LAYOUT>(0, lr_t, q, ROWS, ZROW, abase);
-    }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[rt * 64 + lane];
     ex8 av[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
@@ -729,9 +751,9 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, int lr, int
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kc == 7) {
-                int lr_t = lr;
-                asm volatile("" : "+v"(lr_t));
-                tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
+                const int nt = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(nt * RT + rt) * 64 + lane];
             }
             if (kc == 4) {
 #pragma unroll
@@ -769,6 +791,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     constexpr int LAYER_FRAGS = TAPS * 8 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* hscratch = reinterpret_cast<float*>(lds + 8 * PLANE);  // [2][RT*16] head pre-activations
+    int* tap_table = reinterpret_cast<int*>(lds + 8 * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes]
     const int count = a.count_dev ? *a.count_dev : a.count_host;
     const int pos0 = blockIdx.x * P;
     if (pos0 >= count) return;
@@ -805,6 +828,14 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         const int plane = i >> 5, zr = (i >> 2) & 7, pc = i & 3;
         *reinterpret_cast<uint4*>(lds + plane * PLANE + (ZROW + zr) * LDS_ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
     }
+    if (wave == 7) {  // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier)
+        for (int tap = 0; tap < TAPS; tap++) {
+            int tb[RT];
+            tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = tb[rt];
+        }
+    }
     int obase[RN];
 #pragma unroll
     for (int j = 0; j < RN; j++) obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
@@ -822,9 +853,8 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         __syncthreads();
         for (int tap = 0; tap < TAPS; tap++) {
             int abase[RT];
-            int lr_t = lr;
-            asm volatile("" : "+v"(lr_t));
-            tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr_t, q, ROWS, ZROW, abase);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
             for (int kc = 0; kc < a.kc_in; kc++) {
                 ex8 b[RN];
 #pragma unroll
@@ -861,7 +891,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             }
         }
         __syncthreads();
-        k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET>(lds, lr, q, acc, [&](int tap, int kc, int j) -> ex8 {
+        k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, acc, [&](int tap, int kc, int j) -> ex8 {
             const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
             return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
         });
@@ -950,7 +980,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) pacc[rt][j] = b4;
         }
-        k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, lr, q, pacc, [&](int tap, int kc, int j) -> ex8 {
+        k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, [&](int tap, int kc, int j) -> ex8 {
             const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
             return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
         });
@@ -1578,7 +1608,7 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
 template <int NB, int OPT = 0, typename ET = __bf16>
 int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
-    const size_t smem = (size_t)LROWS * LDS_ROWB * 8;
+    const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + ((OPT & 4096) ? (size_t)9 * RT * 64 * 4 : 0);
     auto kern = tower_mfma_kernel<NB, P, OPT, ET>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1623,7 +1653,7 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
 template <int NB, int RNP, typename ET>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
-    const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float);
+    const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
     auto kern = net_mfma_kernel<NB, P, RNP, ET>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2152,6 +2182,7 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 512: r = launch_tower<5, 512>(a, positions, net->stream); break;
                 case 1024: r = launch_tower<5, 1024>(a, positions, net->stream); break;
                 case 2048: r = launch_tower<5, 2048>(a, positions, net->stream); break;
+                case 4224: r = launch_tower<5, 4224>(a, positions, net->stream); break;  // 4096 + 128
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
