@@ -2182,7 +2182,11 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 512: r = launch_tower<5, 512>(a, positions, net->stream); break;
                 case 1024: r = launch_tower<5, 1024>(a, positions, net->stream); break;
                 case 2048: r = launch_tower<5, 2048>(a, positions, net->stream); break;
-                case 4224: r = launch_tower<5, 4224>(a, positions, net->stream); break;  // 4096 + 128
+                case 4224: r = launch_tower<5, 4224>(a, positions, net->stream); break;  // 4096 + 128 = the shipped loop
+                case 4240: r = launch_tower<5, 4240>(a, positions, net->stream); break;  // ... without activation reads
+                case 4256: r = launch_tower<5, 4256>(a, positions, net->stream); break;  // ... without the weight stream
+                case 4272: r = launch_tower<5, 4272>(a, positions, net->stream); break;  // ... without both
+                case 4336: r = launch_tower<5, 4336>(a, positions, net->stream); break;  // ... MFMAs, barriers only
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
