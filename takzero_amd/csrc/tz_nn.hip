@@ -1633,10 +1633,11 @@ int tower_bf16(tz_net* net, const void* in, void* out, const int32_t* count_dev,
     a.nlayers = 2 * net->blocks;
     const bool h = net->precision == TZ_PREC_F16;
     switch (net->n) {
-        case 3: return h ? launch_tower<3, 0, _Float16>(a, max_positions, st) : launch_tower<3>(a, max_positions, st);
-        case 4: return h ? launch_tower<4, 0, _Float16>(a, max_positions, st) : launch_tower<4>(a, max_positions, st);
-        case 5: return h ? launch_tower<5, 0, _Float16>(a, max_positions, st) : launch_tower<5>(a, max_positions, st);
-        case 6: return h ? launch_tower<6, 0, _Float16>(a, max_positions, st) : launch_tower<6>(a, max_positions, st);
+        // OPT 4224 = tap table in LDS + pinned issue order: the loop the net kernel ships (see tz_debug_tower_bench)
+        case 3: return h ? launch_tower<3, 4224, _Float16>(a, max_positions, st) : launch_tower<3, 4224>(a, max_positions, st);
+        case 4: return h ? launch_tower<4, 4224, _Float16>(a, max_positions, st) : launch_tower<4, 4224>(a, max_positions, st);
+        case 5: return h ? launch_tower<5, 4224, _Float16>(a, max_positions, st) : launch_tower<5, 4224>(a, max_positions, st);
+        case 6: return h ? launch_tower<6, 4224, _Float16>(a, max_positions, st) : launch_tower<6, 4224>(a, max_positions, st);
     }
     return tz_fail(TZ_EINVAL, "tower: unsupported board size");
 }
