@@ -2188,6 +2188,7 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 4256: r = launch_tower<5, 4256>(a, positions, net->stream); break;  // ... without the weight stream
                 case 4272: r = launch_tower<5, 4272>(a, positions, net->stream); break;  // ... without both
                 case 4336: r = launch_tower<5, 4336>(a, positions, net->stream); break;  // ... MFMAs, barriers only
+                case 4288: r = launch_tower<5, 4288>(a, positions, net->stream); break;  // shipped loop without the layer epilogue
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
