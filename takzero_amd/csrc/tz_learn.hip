@@ -55,32 +55,39 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
     const float* ap = AT ? A + (size_t)(16 * g + ak) * lda + m0 + am : A + (m0 + am) * lda + 16 * g + ak;
     const float* bp = B + (size_t)(16 * g + bk) * ldb + n0 + bn;
     const size_t astep = AT ? (size_t)32 * lda : 32, bstep = (size_t)32 * ldb;
-    // gather state, kept incrementally (no division in the loop).  !AT: this thread's pixel is fixed (row m0+am), its
-    // k = tap*gc + c advances by 32 per step.  AT: its 4 k-indices are fixed (m0+am..+3 = one tap, 4 channels), its
-    // pixel advances by 32 per step.
+    // gather state.  The address arithmetic of the im2col view is taken out of the loop (integer VALU work inside an MFMA
+    // loop is expensive: it competes with the other wave of the SIMD for issue slots): a small LDS table holds, for every
+    // (tap, pixel of a board), the offset of the source pixel or -1 off the board; per step a thread advances one counter,
+    // reads one table entry and adds.
+    //   !AT: the thread's pixel is fixed (row m0+am), its k = tap*gc + c advances by 32 per step.
+    //   AT : its 4 k-indices are fixed (m0+am..+3 = one tap, 4 channels), its pixel advances by 32 per step.
+    __shared__ int srcoff[9][40];   // [tap][pixel in board] -> (source pixel in board) * gc, or -1
     const int gnn = gn * gn;
-    const int inv_n = 65536 / (gn > 0 ? gn : 1) + 1;   // q / gn == (q * inv_n) >> 16 for q < 64
     int g_b = 0, g_lp = 0, g_tap = 0, g_c = 0;          // board, pixel inside the board, tap, channel
     if (GATHER) {
+        for (int i = threadIdx.x; i < 9 * gnn; i += 512) {
+            const int tap = i / gnn, lp = i - tap * gnn, y = lp / gn + tap / 3 - 1, x = lp % gn + tap % 3 - 1;
+            srcoff[tap][lp] = (y >= 0 && y < gn && x >= 0 && x < gn) ? (y * gn + x) * gc : -1;
+        }
         const int pix = AT ? 16 * g + ak : (int)m0 + am, k = AT ? (int)m0 + am : 16 * g + ak;
         g_b = pix / gnn;
         g_lp = pix - g_b * gnn;
         g_tap = k / gc;            // >= 9 marks the K padding
         g_c = k - g_tap * gc;
+        __syncthreads();
     }
+    const float* g_row = A + (size_t)g_b * gnn * gc;    // start of the thread's current board
     auto gather = [&]() -> float4 {
-        if (g_tap >= 9) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const int py = (g_lp * inv_n) >> 16, t3 = (g_tap * 11) >> 5;   // tap / 3
-        const int y = py + t3 - 1, x = g_lp - py * gn + (g_tap - 3 * t3) - 1;
-        if (y < 0 || y >= gn || x < 0 || x >= gn) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *(const float4*)(A + ((size_t)g_b * gnn + y * gn + x) * gc + g_c);
+        const int off = g_tap < 9 ? srcoff[g_tap][g_lp] : -1;
+        if (off < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *(const float4*)(g_row + off + g_c);
     };
     auto gather_advance = [&]() {
         if (AT) {
             g_lp += 32;
             while (g_lp >= gnn) {
                 g_lp -= gnn;
-                g_b++;
+                g_row += gnn * gc;
             }
         } else {
             g_c += 32;
