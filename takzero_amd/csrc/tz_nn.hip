@@ -589,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                         tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap + 1 < TAPS ? tap + 1 : tap, lr_t, q, ROWS, ZROW, abase);
                     }
                 }
-                if (kc == 4) {
+                if (kc == 4 && !(OPT & 8192)) {  // OPT 8192 (timing ablation only, wrong planes): no mid-tap rebase
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
                         abase[rt] += 4 * PLANE;
@@ -2189,6 +2189,7 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 4272: r = launch_tower<5, 4272>(a, positions, net->stream); break;  // ... without both
                 case 4336: r = launch_tower<5, 4336>(a, positions, net->stream); break;  // ... MFMAs, barriers only
                 case 4288: r = launch_tower<5, 4288>(a, positions, net->stream); break;  // shipped loop without the layer epilogue
+                case 12416: r = launch_tower<5, 12416>(a, positions, net->stream); break;  // shipped loop without the mid-tap rebase adds
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
