@@ -459,8 +459,15 @@ struct TowerArgs {
     int nlayers;         // 2 * blocks
 };
 
-// OPT: bit 0 = fetch the next layer's first weight fragments during the last two k-steps (A/B switch for
-// tz_debug_tower_bench; shipped value in launch_tower)
+// OPT: A/B and ablation switches for tz_debug_tower_bench (tools/tower_bench.py); tower_bf16 ships 4224 = 4096 | 128.
+//   1     fetch the next layer's first weight fragments during the last two k-steps            (no gain)
+//   2, 4  stagger the two waves of a SIMD by s_sleep 4 / 10                                      (no gain)
+//   8     weight prefetch distance 3 instead of 2                                                (no gain)
+//   16, 32, 64   ablations: no activation-fragment reads / no weight stream / no layer epilogue  (timing only)
+//   128   pinned issue order: MFMAs of a row tile, then the ds_read refilling its fragment       (+1 %, shipped)
+//   256, 512, 1024, 2048   other issue orders: reads one tile behind / 4:2 / VALU slots / floating weight loads (worse)
+//   4096  per-tap fragment base addresses from a table in LDS instead of recomputing them        (+10 %, shipped)
+//   8192  ablation: no mid-tap rebase adds                                                        (timing only, no effect)
 template <int NB, int P, int OPT = 0, typename ET = __bf16>
 __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
     typedef typename Elem<ET>::x8 ex8;
