@@ -700,6 +700,175 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A/B twin of the tower (tz_debug_tower_bench variant 100000): the 8 waves are 4 channel groups (64 output channels =
+// 4 column tiles each) x 2 row halves (row tiles 0..6 and 7..12 for 13 tiles), so that an activation fragment read from
+// LDS feeds 4 MFMAs instead of 2 (half the ds_read bytes) at 28 accumulator tiles per wave; the two waves of a channel
+// group fetch the same weight fragments (the second fetch comes from the vector L1).  Waves w and w+4 share a SIMD and
+// are one wave of each half, so the SIMD's MFMA count per k-step is unchanged.
+template <int NB, int P, int RTW, typename ET>
+__device__ __forceinline__ void tower4x2_body(const TowerArgs& a, unsigned char* lds, const int* tap_table, int lane, int cg, int tile0,
+                                              int valid_rows, size_t m0) {
+    typedef typename Elem<ET>::x8 ex8;
+    typedef typename Elem<ET>::x4 ex4;
+    constexpr int RN = 4, TAPS = 9;
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8;
+    constexpr int PLANE = LROWS * LDS_ROWB;
+    constexpr int LAYER_FRAGS = TAPS * 8 * 16;
+    const int q = lane >> 4, lr = lane & 15;
+    const int ct0 = cg * RN;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    const int lane16 = lane * 16;
+    auto wload = [&](int layer, int tap, int kc, int j) -> ex8 {
+        const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
+        return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
+    };
+    int obase[RN];  // this lane's 4 channels of column tile j, row lr of row tile tile0
+#pragma unroll
+    for (int j = 0; j < RN; j++)
+        obase[j] = (cg * 2 + (j >> 1)) * PLANE + (tile0 * 16 + lr) * LDS_ROWB + lds_piece(lr, (j & 1) * 2 + (q >> 1)) + (q & 1) * 8;
+    f32x4 acc[RTW][RN];
+    ex8 bq[4][RN];
+    for (int layer = 0; layer < a.nlayers; layer++) {
+        if ((layer & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + layer * FILTERS + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++) acc[rt][j] = b4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            bq[0][j] = wload(layer, 0, 0, j);
+            bq[1][j] = wload(layer, 0, 1, j);
+        }
+        __syncthreads();
+        int abase[RTW];
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++) abase[rt] = tap_table[(tile0 + rt) * 64 + lane];
+        ex8 av[RTW];
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+        for (int tap = 0; tap < TAPS; tap++) {
+#pragma unroll
+            for (int kc = 0; kc < 8; kc++) {
+                if (kc + 2 < 8) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap, kc + 2, j);
+                } else if (tap + 1 < TAPS) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++) bq[(kc + 2) & 3][j] = wload(layer, tap + 1, kc + 2 - 8, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc == 7) {
+                    const int nt = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+                    for (int rt = 0; rt < RTW; rt++) abase[rt] = tap_table[(nt * RT + tile0 + rt) * 64 + lane];
+                }
+                if (kc == 4) {
+#pragma unroll
+                    for (int rt = 0; rt < RTW; rt++) {
+                        abase[rt] += 4 * PLANE;
+                        asm volatile("" : "+v"(abase[rt]));
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++) {
+#pragma unroll
+                    for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
+                    if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
+                    else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, RN, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+        if (layer + 1 == a.nlayers) {
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const int cbase = (ct0 + j) * 16 + q * 4;
+#pragma unroll
+                for (int rt = 0; rt < RTW; rt++) {
+                    const int r = (tile0 + rt) * 16 + lr;
+                    ex4 pk;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    if (r < valid_rows) *reinterpret_cast<ex4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
+                }
+            }
+            break;
+        }
+        __syncthreads();
+        const bool to_second = (layer & 1) == 0;
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (to_second) b4 = *reinterpret_cast<const f32x4*>(a.bias + (layer + 1) * FILTERS + (ct0 + j) * 16 + q * 4);
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++) {
+                ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
+                ex4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                if (to_second) {
+                    const ex4 xv = *slot;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
+                }
+                *slot = pk;
+            }
+        }
+    }
+}
+
+template <int NB, int P, typename ET = __bf16>
+__global__ __launch_bounds__(512, 2) void tower4x2_mfma_kernel(TowerArgs a) {
+    constexpr int TAPS = 9, LAYOUT = 1, NT = 512;
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
+    constexpr int PLANE = LROWS * LDS_ROWB;
+    constexpr int RT_A = (RT + 1) / 2, RT_B = RT - RT_A;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int count = a.count_dev ? *a.count_dev : a.count_host;
+    const int pos0 = blockIdx.x * P;
+    if (pos0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, lr = lane & 15;
+    const int valid_rows = min(ROWS, (count - pos0) * NN);
+    const size_t m0 = (size_t)pos0 * NN;
+    {
+        constexpr int NLOAD = (LROWS * 32 + NT - 1) / NT;
+        uint4 v[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (row < valid_rows) v[i] = *reinterpret_cast<const uint4*>(a.in + (m0 + row) * 256 + ci * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; i++) {
+            const int id = tid + i * NT, row = id >> 5, ci = id & 31;
+            if (row < LROWS) *reinterpret_cast<uint4*>(lds + LdsImg<LAYOUT>::store_addr(row, ci, PLANE)) = v[i];
+        }
+    }
+    int* tap_table = reinterpret_cast<int*>(lds + 8 * PLANE);
+    if (wave == 0) {
+        for (int tap = 0; tap < TAPS; tap++) {
+            int tb[RT];
+            tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = tb[rt];
+        }
+    }
+    if (wave < 4) tower4x2_body<NB, P, RT_A, ET>(a, lds, tap_table, lane, wave, 0, valid_rows, m0);
+    else tower4x2_body<NB, P, RT_B, ET>(a, lds, tap_table, lane, wave - 4, RT_A, valid_rows, m0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The whole trunk and its heads in ONE launch: game_repr + first conv (net5.rs:46-64), the residual tower, the policy
 // conv (net5.rs:75-87) and the value / UBE heads (net5.rs:89-120).  Same structure as tower_mfma_kernel; what
 // enters is the packed game states, what leaves is the policy tensor (fp32), value and UBE.  The block input of the
@@ -1612,6 +1781,22 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     return conv_dispatch<__bf16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
 }
 
+template <int NB>
+int launch_tower4x2(const TowerArgs& a, int max_positions, hipStream_t st) {
+    constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
+    const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + (size_t)9 * RT * 64 * 4;
+    auto kern = tower4x2_mfma_kernel<NB, P>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((max_positions + P - 1) / P), dim3(512), smem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tower4x2 launch: ") + hipGetErrorString(e));
+    return TZ_OK;
+}
+
 template <int NB, int OPT = 0, typename ET = __bf16>
 int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
@@ -2197,6 +2382,7 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 4336: r = launch_tower<5, 4336>(a, positions, net->stream); break;  // ... MFMAs, barriers only
                 case 4288: r = launch_tower<5, 4288>(a, positions, net->stream); break;  // shipped loop without the layer epilogue
                 case 12416: r = launch_tower<5, 12416>(a, positions, net->stream); break;  // shipped loop without the mid-tap rebase adds
+                case 100000: r = launch_tower4x2<5>(a, positions, net->stream); break;     // 4 channel groups x 2 row halves
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
@@ -2212,6 +2398,16 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_out = ms / iters;
+    if (getenv("TZ_TOWER_BENCH_CHECKSUM")) {  // A/B variants must agree: print a checksum of the output of the last launch
+        std::vector<uint16_t> h((size_t)positions * 25 * FILTERS);
+        TZ_HIP(hipMemcpy(h.data(), net->act_b, h.size() * 2, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0, x = 1469598103934665603ull;
+        for (uint16_t v : h) {
+            sum += v;
+            x = (x ^ v) * 1099511628211ull;
+        }
+        fprintf(stderr, "tower variant %d: output sum %llu hash %016llx\n", variant, sum, x);
+    }
     return TZ_OK;
 }
 
