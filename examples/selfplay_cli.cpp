@@ -92,9 +92,10 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     CHECK(tz_selfplay_run(sp, directory.c_str(), moves, 32000, "", reload_model, &reload, wait_limit));
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    unsigned long long played = 0, targets = 0, replays = 0, simulations = 0, evals = 0;
+    unsigned long long played = 0, targets = 0, replays = 0, simulations = 0, evals = 0, skipped = 0;
     CHECK(tz_selfplay_counters(sp, (uint64_t*)&played, (uint64_t*)&targets, (uint64_t*)&replays));
     CHECK(tz_search_counters(mcts, (uint64_t*)&simulations, (uint64_t*)&evals));
+    CHECK(tz_search_pool_overflows(mcts, (uint64_t*)&skipped));
     long rss_kb = 0;   // resident set of this process (host memory of the driver: move history, text buffers)
     if (FILE* f = fopen("/proc/self/status", "r")) {
         char line[256];
@@ -102,8 +103,8 @@ int main(int argc, char** argv) {
             if (sscanf(line, "VmRSS: %ld kB", &rss_kb) == 1) break;
         fclose(f);
     }
-    printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f rss_mb %ld\n",
-           played, targets, replays, simulations, evals, reload.reloads, seconds, (double)simulations / seconds, rss_kb / 1024);
+    printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f rss_mb %ld skipped_expansions %llu\n",
+           played, targets, replays, simulations, evals, reload.reloads, seconds, (double)simulations / seconds, rss_kb / 1024, skipped);
     tz_selfplay_destroy(sp);
     tz_search_destroy(mcts);
     tz_net_destroy(net);

@@ -219,6 +219,12 @@ int tz_search_gumbel_sh(tz_search* s, const float* betas, int sampled_actions, i
                         const float* gumbel, int amax, uint16_t* selected_out);
 /* counters since creation: simulations (incl. Known hits) and network-evaluated leaves */
 int tz_search_counters(tz_search* s, uint64_t* simulations, uint64_t* nn_leaf_evals);
+/* The reference's trees are heap allocated and unbounded; a game's node pool here has `node_capacity` slots (default
+ * 262 144 on 5x5: 66 GB for 4096 games).  When a leaf cannot get its children because the pool is full it is evaluated
+ * and backed up without being expanded (it stays a leaf; the next tz_search_step compacts the kept subtree and frees
+ * the rest), and the event is counted here.  With TZ_STRICT_CAPACITY set in the environment at creation a full pool is
+ * TZ_ECAPACITY instead. */
+int tz_search_pool_overflows(tz_search* s, uint64_t* skipped_expansions);
 /* node slots in use in the fullest game's pool, and the per-game capacity */
 int tz_search_pool_usage(tz_search* s, uint32_t* max_used, uint32_t* capacity);
 int tz_search_sync(tz_search* s);

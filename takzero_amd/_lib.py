@@ -35,7 +35,7 @@ SYMBOLS = [
     "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
     "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
     "tz_selfplay_run", "tz_reanalyze_create", "tz_reanalyze_destroy", "tz_reanalyze_feed", "tz_reanalyze_iterate",
-    "tz_reanalyze_take_text", "tz_reanalyze_run", "tz_compete", "tz_puzzle_benchmark",
+    "tz_reanalyze_take_text", "tz_reanalyze_run", "tz_compete", "tz_puzzle_benchmark", "tz_search_pool_overflows",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def load():
     lib.tz_search_gumbel_sh.argtypes = [vp, vp, ci, ci, vp, ci, vp]
     lib.tz_search_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.tz_search_sync.argtypes = [vp]
+    lib.tz_search_pool_overflows.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.tz_search_pool_usage.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.tz_search_profile.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64)]

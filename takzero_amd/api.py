@@ -397,6 +397,12 @@ class BatchedMCTS:
         check(self.lib.tz_search_pool_usage(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def pool_overflows(self):
+        """expansions skipped because a game's node pool was full (see tz_search_pool_overflows)"""
+        c = C.c_uint64()
+        check(self.lib.tz_search_pool_overflows(self.h, C.byref(c)))
+        return c.value
+
     def sync(self):
         check(self.lib.tz_search_sync(self.h))
 

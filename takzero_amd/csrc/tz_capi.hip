@@ -40,7 +40,8 @@ struct tz_search {
 
 namespace {
 
-int default_capacity(int n) { return n <= 3 ? 16384 : n == 4 ? 65536 : n == 5 ? 131072 : 262144; }
+// node slots per game and bank; 62 B each: 4096 games of 5x5 = 66 GB, 2048 games of 6x6 = 66 GB of the 288 GB
+int default_capacity(int n) { return n <= 3 ? 16384 : n == 4 ? 65536 : n == 5 ? 262144 : 524288; }
 int default_max_actions(int n) { return n <= 3 ? 64 : n == 4 ? 192 : n == 5 ? 512 : 1024; }
 
 template <typename T>
@@ -209,6 +210,7 @@ int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int ha
     d.n = board_n;
     d.half_komi = half_komi;
     d.cap = node_capacity > 0 ? node_capacity : default_capacity(board_n);
+    d.strict_capacity = getenv("TZ_STRICT_CAPACITY") != nullptr;
     d.max_actions = default_max_actions(board_n);
     d.agent_kind = agent_kind;
     const size_t nodes = (size_t)2 * batch * d.cap;
@@ -236,7 +238,7 @@ int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int ha
     rc |= dev_alloc(&d.nn_game, batch);
     rc |= dev_alloc(&d.nn_count, 1);
     rc |= dev_alloc(&d.bfs_src, (size_t)batch * d.cap);
-    rc |= dev_alloc(&d.counters, 2);
+    rc |= dev_alloc(&d.counters, 3);
     rc |= dev_alloc(&d.error_flag, 1);
     rc |= dev_alloc(&d.term_reason, batch);
     rc |= dev_alloc(&d.term_winner, batch);
@@ -253,7 +255,7 @@ int tz_search_create(tz_net* net, int agent_kind, int batch, int board_n, int ha
     TZ_HIP(hipMemsetAsync(d.leaf_env, 0, (size_t)batch * sizeof(tz_state), s->stream));
     TZ_HIP(hipMemsetAsync(d.betas, 0, batch * sizeof(float), s->stream));
     TZ_HIP(hipMemsetAsync(d.start_node, 0, batch * sizeof(int32_t), s->stream));
-    TZ_HIP(hipMemsetAsync(d.counters, 0, 2 * sizeof(unsigned long long), s->stream));
+    TZ_HIP(hipMemsetAsync(d.counters, 0, 3 * sizeof(unsigned long long), s->stream));
     TZ_HIP(hipMemsetAsync(d.error_flag, 0, 4, s->stream));
     TZ_HIP(hipMemsetAsync(d.nn_count, 0, 4, s->stream));
     if (s->net && (rc = tz_net_ensure_batch(s->net, batch))) {
@@ -635,6 +637,16 @@ int tz_search_gumbel_sh(tz_search* s, const float* betas, int sampled_actions, i
     for (int g = 0; g < B; g++) selected_out[g] = moves[(size_t)g * r.amax + sets[g][0].child];
     if ((rc = tz_tree_gumbel_root_fixup(s->d, s->stream))) return rc;
     TZ_HIP(hipStreamSynchronize(s->stream));
+    return TZ_OK;
+}
+
+int tz_search_pool_overflows(tz_search* s, uint64_t* skipped_expansions) {
+    if (!s || !skipped_expansions) return tz_fail(TZ_EINVAL, "tz_search_pool_overflows: null argument");
+    TZ_HIP(hipSetDevice(s->device));
+    unsigned long long c = 0;
+    TZ_HIP(hipMemcpyAsync(&c, s->d.counters + 2, sizeof c, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipStreamSynchronize(s->stream));
+    *skipped_expansions = c;
     return TZ_OK;
 }
 

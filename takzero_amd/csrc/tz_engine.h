@@ -39,6 +39,7 @@ struct TreeArrays {
 
 struct SearchDev {
     int batch, n, half_komi, cap, max_actions, agent_kind;
+    int strict_capacity;  // 1: a full node pool is an error (TZ_ECAPACITY); 0: the leaf is evaluated but not expanded, and counted
     TreeArrays t;       // arrays of size 2 * batch * cap
     uint8_t* bank;      // [batch] current bank of each game
     uint32_t* alloc;    // [batch] next free slot in the current bank
@@ -55,7 +56,7 @@ struct SearchDev {
     int32_t* nn_game;     // [batch] compacted list of games that need the network
     int32_t* nn_count;    // [1]
     uint32_t* bfs_src;    // [batch][cap] scratch for subtree compaction
-    unsigned long long* counters;  // [0] simulations, [1] nn leaf evals
+    unsigned long long* counters;  // [0] simulations, [1] nn leaf evals, [2] expansions skipped because a game's pool was full
     int32_t* error_flag;  // [1] sticky: 1 node pool overflow, 2 depth overflow, 3 action overflow
     int8_t* term_reason;  // [batch] reason of the last terminal seen by restart_kernel (0 none, 1 road, 2 flats, 3 reversible plies)
     uint8_t* term_winner; // [batch] 0 white, 1 black, 2 draw

@@ -407,13 +407,17 @@ __global__ __launch_bounds__(64) void expand_kernel(SearchDev s, NetOut out) {
     float sd = s.t.std_dev[base + leaf];
     sd = sd + (-sd + sqrtf(variance)) / n;
     const uint32_t c0 = s.alloc[g];
-    if (c0 + (uint32_t)nact > (uint32_t)s.cap) {
+    // The reference's trees live on the heap and are unbounded; a game's pool here is not.  A full pool is either an
+    // error (strict) or the leaf is evaluated and backed up without getting children: it stays a leaf, is simply
+    // evaluated again when it is reached again, and the next `step` compacts the kept subtree and frees the rest.
+    const bool full = c0 + (uint32_t)nact > (uint32_t)s.cap;
+    if (full && s.strict_capacity) {
         if (l == 0) atomicMax(s.error_flag, 1);
         return;
     }
     // children, node/mod.rs:66-79
     const uint32_t child_bits = tz_float_to_bits(-mean);
-    for (int i = l; i < nact; i += 64) {
+    for (int i = l; i < (full ? 0 : nact); i += 64) {
         const size_t ci = base + c0 + i;
         s.t.eval_tag[ci] = TZ_EVAL_VALUE;
         s.t.eval_bits[ci] = child_bits;
@@ -426,11 +430,15 @@ __global__ __launch_bounds__(64) void expand_kernel(SearchDev s, NetOut out) {
         s.t.action[ci] = acts[i];
     }
     if (l == 0) {
-        s.alloc[g] = c0 + (uint32_t)nact;
         s.t.eval_bits[base + leaf] = tz_float_to_bits(mean);
         s.t.std_dev[base + leaf] = sd;
-        s.t.child0[base + leaf] = c0;
-        s.t.nchild[base + leaf] = (uint16_t)nact;
+        if (full) {
+            atomicAdd(&s.counters[2], 1ull);
+        } else {
+            s.alloc[g] = c0 + (uint32_t)nact;
+            s.t.child0[base + leaf] = c0;
+            s.t.nchild[base + leaf] = (uint16_t)nact;
+        }
     }
     __syncthreads();
     backup(s, base, tnode, tvis, len - 1, ev_value(value * TZ_DISCOUNT), variance * TZ_DISCOUNT * TZ_DISCOUNT, ev_value(mean));

@@ -187,12 +187,25 @@ def test_gumbel_sequential_halving_bit_exact(oracle):
         assert np.array_equal(gpu.restart_terminal_envs(choice), ora.restart_terminal(choice))
 
 
-def test_capacity_error_is_reported(oracle):
+def test_full_node_pool_degrades_or_errors(oracle, monkeypatch):
+    """The reference's trees are unbounded; a pool here is not.  Default: the search goes on (the leaf is evaluated, not
+    expanded) and the event is counted; TZ_STRICT_CAPACITY: TZ_ECAPACITY."""
     A = require_gpu()
-    gpu = A.BatchedMCTS(4, 5, 4, agent_kind=A.AGENT_DUMMY, node_capacity=64)
+    gpu = A.BatchedMCTS(4, 5, 4, agent_kind=A.AGENT_DUMMY, node_capacity=256)   # room for the root's children and two more nodes'
     gpu.new_openings(np.zeros(4, np.int32))
+    gpu.simulate(np.zeros(4, np.float32), 20)
+    info = gpu.root_info()
+    assert gpu.pool_overflows() > 0 and np.array_equal(info["visit_count"], np.full(4, 20, np.uint32))
+    ch = gpu.root_children()
+    assert np.array_equal(ch["visits"].sum(axis=1), np.full(4, 19))   # every simulation after the first went through a child
+    acts = gpu.select_best_actions()
+    gpu.step(acts)                                                    # and the game goes on
+    gpu.simulate(np.zeros(4, np.float32), 5)
+    monkeypatch.setenv("TZ_STRICT_CAPACITY", "1")
+    strict = A.BatchedMCTS(4, 5, 4, agent_kind=A.AGENT_DUMMY, node_capacity=256)
+    strict.new_openings(np.zeros(4, np.int32))
     with pytest.raises(A.TakzeroError) as e:
-        gpu.simulate(np.zeros(4, np.float32), 20)
+        strict.simulate(np.zeros(4, np.float32), 20)
     assert e.value.code == -5
 
 
