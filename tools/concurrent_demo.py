@@ -41,7 +41,7 @@ if role == "learn":
         log("done after %d logged steps" % steps)
 else:
     net = A.Net.new(arch=A.ARCH_NET5, seed=1)
-    mcts = A.BatchedMCTS(2048, 5, 4, agent=net, node_capacity=1 << 16)
+    mcts = A.BatchedMCTS(2048, 5, 4, agent=net)
     while not os.path.exists(os.path.join(d, "model_latest.ot")) or not os.path.exists(os.path.join(d, "buffer_lengths.txt")):
         time.sleep(0.5)
     # one long native run each (the progress lines come from tools/concurrent_demo.sh watching the files)
