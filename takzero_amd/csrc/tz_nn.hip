@@ -468,6 +468,7 @@ struct TowerArgs {
 //   256, 512, 1024, 2048   other issue orders: reads one tile behind / 4:2 / VALU slots / floating weight loads (worse)
 //   4096  per-tap fragment base addresses from a table in LDS instead of recomputing them        (+10 %, shipped)
 //   8192  ablation: no mid-tap rebase adds                                                        (timing only, no effect)
+//   16384, 32768, 65536   cache policy of the weight loads: sc0 / sc1 / nt                          (0 %, -1 %, 0 %)
 template <int NB, int P, int OPT = 0, typename ET = __bf16>
 __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
     typedef typename Elem<ET>::x8 ex8;
@@ -489,9 +490,11 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
     const int lane16 = lane * 16;
+    // A/B: cache policy of the weight stream (aux bits of the buffer load: 1 = sc0, 2 = sc1, 4 = nt)
+    constexpr int WAUX = (OPT & 16384) ? 1 : (OPT & 32768) ? 2 : (OPT & 65536) ? 4 : 0;
     auto wload = [&](int layer, int tap, int kc, int j) -> ex8 {
         const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
-        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0);
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, WAUX);
         return __builtin_bit_cast(ex8, r);
     };
     {   // tower input tile: every load in flight before the first LDS store
@@ -2383,6 +2386,9 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 4288: r = launch_tower<5, 4288>(a, positions, net->stream); break;  // shipped loop without the layer epilogue
                 case 12416: r = launch_tower<5, 12416>(a, positions, net->stream); break;  // shipped loop without the mid-tap rebase adds
                 case 100000: r = launch_tower4x2<5>(a, positions, net->stream); break;     // 4 channel groups x 2 row halves
+                case 20608: r = launch_tower<5, 20608>(a, positions, net->stream); break;   // shipped loop, weight loads sc0
+                case 36992: r = launch_tower<5, 36992>(a, positions, net->stream); break;   // ... sc1
+                case 69760: r = launch_tower<5, 69760>(a, positions, net->stream); break;   // ... nt
                 default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
             }
         }
