@@ -2386,6 +2386,9 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 4288: r = launch_tower<5, 4288>(a, positions, net->stream); break;  // shipped loop without the layer epilogue
                 case 12416: r = launch_tower<5, 12416>(a, positions, net->stream); break;  // shipped loop without the mid-tap rebase adds
                 case 100000: r = launch_tower4x2<5>(a, positions, net->stream); break;     // 4 channel groups x 2 row halves
+                case 4225: r = launch_tower<5, 4225>(a, positions, net->stream); break;     // shipped loop + cross-layer weight prefetch
+                case 4226: r = launch_tower<5, 4226>(a, positions, net->stream); break;     // ... + wave stagger
+                case 4232: r = launch_tower<5, 4232>(a, positions, net->stream); break;     // ... + prefetch distance 3
                 case 20608: r = launch_tower<5, 20608>(a, positions, net->stream); break;   // shipped loop, weight loads sc0
                 case 36992: r = launch_tower<5, 36992>(a, positions, net->stream); break;   // ... sc1
                 case 69760: r = launch_tower<5, 69760>(a, positions, net->stream); break;   // ... nt
