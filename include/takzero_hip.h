@@ -309,6 +309,29 @@ int tz_trainer_step(tz_trainer* t, const tz_state* states, const float* target_p
 /* outputs of the last step's forward_t(xs, true): policy [batch][policy_size], value [batch], ube [batch] (log) */
 int tz_trainer_outputs(tz_trainer* t, float* policy_out, float* value_out, float* ube_out);
 
+/* board size, batch and architecture of a trainer */
+int tz_trainer_shape(tz_trainer* t, int* board_n_out, int* batch_out, int* arch_out);
+
+/* ---------- learn::main above the step (learn/src/main.rs:99-319, 486-516), native host code (csrc/tz_host_learn.cpp) ----------
+ * The two target buffers with forced-use counts (SELFPLAY / REANALYZE_TARGET_FORCED_USES, :59-60) fed by tailing the
+ * target files, create_batch (uniform sampling without replacement, a random board symmetry per target, dense
+ * policy / mask tensors) and the training loop with buffer_lengths.txt.  which: 0 selfplay, 1 reanalyze. */
+typedef struct tz_learn tz_learn;
+int tz_learn_create(tz_trainer* trainer, int half_komi, uint64_t seed, int selfplay_forced_uses, int reanalyze_forced_uses,
+                    tz_learn** out);
+int tz_learn_destroy(tz_learn* l);
+int tz_learn_feed(tz_learn* l, int which, const char* path, int model_steps, uint64_t* added_out);
+int tz_learn_add_lines(tz_learn* l, int which, const char* text, uint64_t len, int model_steps, uint64_t* added_out);
+int tz_learn_buffer_len(tz_learn* l, int which, uint64_t* len_out);
+int tz_learn_step(tz_learn* l, int using_reanalyze, int train_ube, int augment, float* losses_out);
+/* Diagnostic: the tensors of the batch tz_learn_step built last (any pointer may be NULL) */
+int tz_learn_last_batch(tz_learn* l, tz_state* states_out, float* policy_out, uint8_t* mask_out, float* value_out, float* ube_out);
+/* the main loop (:172-269); on_step(user, model_steps, losses[3], batch states, batch) runs after every step (save
+ * points and SimHash update_counts live there); a non-zero return stops the loop */
+int tz_learn_run(tz_learn* l, const char* directory, int64_t starting_steps, int64_t steps, int min_selfplay, int min_reanalyze,
+                 int64_t steps_before_reanalyze, double read_interval_s, double sleep_s, double wait_limit_s,
+                 int (*on_step)(void*, int64_t, const float*, const tz_state*, int), void* user, int64_t* model_steps_out);
+
 /* Diagnostic: evaluates on the device the f32 primitives the tree kernels must compute exactly as
  * the host does (op 0 exp, 1 ln, 2 sqrt, 3 a/b, 4 0.997^int(a), 5 (a+b)*a). */
 int tz_device_math(int op, const float* a, const float* b, float* out, int n);

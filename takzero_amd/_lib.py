@@ -35,7 +35,8 @@ SYMBOLS = [
     "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
     "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
     "tz_selfplay_run", "tz_reanalyze_create", "tz_reanalyze_destroy", "tz_reanalyze_feed", "tz_reanalyze_iterate",
-    "tz_reanalyze_take_text", "tz_reanalyze_run", "tz_compete", "tz_puzzle_benchmark", "tz_search_pool_overflows",
+    "tz_reanalyze_take_text", "tz_reanalyze_run", "tz_compete", "tz_puzzle_benchmark", "tz_search_pool_overflows", "tz_trainer_shape",
+    "tz_learn_create", "tz_learn_destroy", "tz_learn_feed", "tz_learn_add_lines", "tz_learn_buffer_len", "tz_learn_step", "tz_learn_run", "tz_learn_last_batch",
 ]
 
 _lib = None
@@ -122,6 +123,16 @@ def load():
     lib.tz_reanalyze_run.argtypes = [vp, C.c_char_p, ci, ci, C.c_char_p, vp, vp, C.c_double]
     lib.tz_compete.argtypes = [vp, vp, vp, cf, cf, C.c_uint64, ci, ci, ci, vp]
     lib.tz_puzzle_benchmark.argtypes = [vp, vp, vp, ci, ci, C.c_uint64, ci, ci, vp]
+    lib.tz_trainer_shape.argtypes = [vp] + [C.POINTER(ci)] * 3
+    lib.tz_learn_create.argtypes = [vp, ci, C.c_uint64, ci, ci, C.POINTER(vp)]
+    lib.tz_learn_destroy.argtypes = [vp]
+    lib.tz_learn_feed.argtypes = [vp, ci, C.c_char_p, ci, C.POINTER(C.c_uint64)]
+    lib.tz_learn_add_lines.argtypes = [vp, ci, vp, C.c_uint64, ci, C.POINTER(C.c_uint64)]
+    lib.tz_learn_buffer_len.argtypes = [vp, ci, C.POINTER(C.c_uint64)]
+    lib.tz_learn_step.argtypes = [vp, ci, ci, ci, vp]
+    lib.tz_learn_last_batch.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.tz_learn_run.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64, ci, ci, C.c_int64, C.c_double, C.c_double, C.c_double, vp, vp,
+                                 C.POINTER(C.c_int64)]
     lib.tz_trainer_create.argtypes = [ci, ci, ci, ci, ci, cf, C.POINTER(vp)]
     lib.tz_trainer_destroy.argtypes = [vp]
     lib.tz_trainer_tensor_count.argtypes = [vp]

@@ -12,6 +12,7 @@ ARCH = "gfx950"
 UNITS = [
     ("tz_text.cpp", ["-ffp-contract=off"]),
     ("tz_host.cpp", ["-ffp-contract=off"]),
+    ("tz_host_learn.cpp", ["-ffp-contract=off"]),
     ("tz_tree.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_capi.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_nn.hip", []),

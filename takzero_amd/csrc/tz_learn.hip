@@ -895,6 +895,14 @@ int tz_trainer_destroy(tz_trainer* t) {
 }
 
 // number of tensors the trainer owns, and the name / element count of tensor i (reference names, `.a.` / `.b.`)
+int tz_trainer_shape(tz_trainer* t, int* board_n_out, int* batch_out, int* arch_out) {
+    if (!t) return tz_fail(TZ_EINVAL, "tz_trainer_shape: null handle");
+    if (board_n_out) *board_n_out = t->n;
+    if (batch_out) *batch_out = t->batch;
+    if (arch_out) *arch_out = t->arch;
+    return TZ_OK;
+}
+
 int tz_trainer_tensor_count(tz_trainer* t) { return t ? (int)t->params.size() : 0; }
 
 int tz_trainer_tensor_info(tz_trainer* t, int i, char* name_out, int name_cap, uint64_t* count_out) {

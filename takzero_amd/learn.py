@@ -349,3 +349,142 @@ def run_learn(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mct
             finally:
                 saver.close()
     return model_steps
+
+
+# ---------------------------------------------------------------------------------------------
+class NativeLearnLoop:
+    """learn::main's buffers, batch construction and training loop in native code (csrc/tz_host_learn.cpp, tz_learn_*)."""
+
+    def __init__(self, trainer, half_komi=4, seed=0, forced_uses=(SELFPLAY_TARGET_FORCED_USES, REANALYZE_TARGET_FORCED_USES)):
+        self.trainer, self.lib = trainer, _lib.load()
+        self.h = C.c_void_p()
+        check(self.lib.tz_learn_create(trainer.h, half_komi, seed, forced_uses[0], forced_uses[1], C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tz_learn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, which, path, model_steps=0):
+        added = C.c_uint64()
+        check(self.lib.tz_learn_feed(self.h, which, str(path).encode(), model_steps, C.byref(added)))
+        return added.value
+
+    def add_lines(self, which, text, model_steps=0):
+        data = text if isinstance(text, bytes) else text.encode()
+        added = C.c_uint64()
+        check(self.lib.tz_learn_add_lines(self.h, which, data, len(data), model_steps, C.byref(added)))
+        return added.value
+
+    def buffer_len(self, which):
+        n = C.c_uint64()
+        check(self.lib.tz_learn_buffer_len(self.h, which, C.byref(n)))
+        return n.value
+
+    def step(self, using_reanalyze=False, train_ube=True, augment=True):
+        losses = np.zeros(3, np.float32)
+        check(self.lib.tz_learn_step(self.h, 1 if using_reanalyze else 0, 1 if train_ube else 0, 1 if augment else 0, losses.ctypes.data))
+        return tuple(float(x) for x in losses)
+
+    def last_batch(self):
+        B, out = self.trainer.batch, api.policy_size(self.trainer.n)
+        states = np.zeros(B, api.STATE_DTYPE)
+        policy, mask = np.zeros((B, out), np.float32), np.zeros((B, out), np.uint8)
+        value, ube = np.zeros(B, np.float32), np.zeros(B, np.float32)
+        check(self.lib.tz_learn_last_batch(self.h, states.ctypes.data, policy.ctypes.data, mask.ctypes.data, value.ctypes.data,
+                                           ube.ctypes.data))
+        return states, policy, mask, value, ube
+
+    def run(self, directory, starting_steps, steps, min_selfplay=MIN_SELFPLAY_BUFFER_LEN, min_reanalyze=MIN_REANALYZE_BUFFER_LEN,
+            steps_before_reanalyze=STEPS_BEFORE_REANALYZE, read_interval=10.0, sleep=30.0, max_wait=None, on_step=None):
+        """tz_learn_run; on_step(model_steps, losses, states) is called after every step."""
+        cb_type = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_int)
+        failure = []
+
+        def trampoline(_user, step_no, losses, states, batch):
+            try:
+                if on_step is not None:
+                    st = np.frombuffer((C.c_char * (batch * api.STATE_DTYPE.itemsize)).from_address(states), dtype=api.STATE_DTYPE)
+                    on_step(int(step_no), (losses[0], losses[1], losses[2]), st)
+                return 0
+            except BaseException as e:   # surfaces after the native loop returns
+                failure.append(e)
+                return 1
+
+        cb = cb_type(trampoline)
+        out = C.c_int64()
+        rc = self.lib.tz_learn_run(self.h, str(directory).encode(), starting_steps, -1 if steps is None else steps, min_selfplay,
+                                   min_reanalyze, steps_before_reanalyze, read_interval, sleep, -1.0 if max_wait is None else max_wait,
+                                   C.cast(cb, C.c_void_p), None, C.byref(out))
+        if failure:
+            raise failure[0]
+        if rc == -6 and "not enough targets" in self.lib.tz_last_error().decode(errors="replace"):
+            raise TimeoutError(self.lib.tz_last_error().decode(errors="replace"))
+        check(rc)
+        return out.value
+
+
+def run_learn_native(directory, trainer, half_komi=4, steps=None, seed=0, pre_train_mcts=None, hash_net=None,
+                     min_selfplay=MIN_SELFPLAY_BUFFER_LEN, min_reanalyze=MIN_REANALYZE_BUFFER_LEN,
+                     steps_before_reanalyze=STEPS_BEFORE_REANALYZE, steps_per_save=STEPS_PER_SAVE,
+                     steps_per_checkpoint=STEPS_PER_CHECKPOINT, pre_training_steps=PRE_TRAINING_STEPS,
+                     initial_targets=INITIAL_RANDOM_TARGETS, read_interval=10.0, sleep=30.0, max_wait=None, log=None):
+    """learn::main (learn/src/main.rs:99-270) with the buffers, batch construction and loop in native code; this function
+    keeps what touches files in the reference's formats through host tools: model discovery / resume and the save
+    points (LibTorch archives)."""
+    import os
+
+    from . import ot
+    from .runner import AsyncAppender
+    from .selfplay import NativeSelfPlay
+
+    saver = AsyncAppender()
+    try:
+        resume = model_path_with_most_steps(directory)
+        if resume is not None:
+            starting_steps = resume[0]
+            trainer.load_tensors(ot.load_ot(resume[1]))
+        else:
+            starting_steps = 0
+            save_model(trainer, os.path.join(directory, "model_0000000.ot"), hash_net)
+            if pre_train_mcts is not None and pre_training_steps > 0:   # pre_training (:425-484)
+                sp = NativeSelfPlay(pre_train_mcts, 0, seed=seed, search="random")
+                lines = []
+                while len(lines) < initial_targets:
+                    sp.play_move()
+                    lines.extend(sp.take_text(0).splitlines(keepends=True))
+                np.random.default_rng([seed, 11]).shuffle(lines)
+                with open(os.path.join(directory, "targets-initial.txt"), "wb") as f:
+                    f.write(b"".join(lines))
+                pre = NativeLearnLoop(trainer, half_komi, seed + 1, forced_uses=(1, 1))   # every target used once
+                pre.add_lines(0, b"".join(lines))
+                for s in range(min(pre_training_steps, len(lines) // trainer.batch)):
+                    losses = pre.step(using_reanalyze=False, train_ube=False, augment=True)
+                    if log and s % 100 == 0:
+                        log("pre-training step %d: %r" % (s, losses))
+                pre.close()
+                starting_steps += pre_training_steps
+                save_model(trainer, os.path.join(directory, "model_%07d.ot" % starting_steps), hash_net)
+        save_model(trainer, os.path.join(directory, "model_latest.ot"), hash_net)
+        loop = NativeLearnLoop(trainer, half_komi, seed)
+
+        def on_step(step_no, losses, states):
+            if hash_net is not None:
+                hash_net.hash_indices(states, update=True)
+            if log:
+                log("step %d: loss_policy %.5f loss_value %.5f loss_ube %.5f" % ((step_no,) + tuple(losses)))
+            if step_no % steps_per_save == 0:
+                save_model(trainer, os.path.join(directory, "model_latest.ot"), hash_net, saver)
+            if step_no % steps_per_checkpoint == 0:
+                save_model(trainer, os.path.join(directory, "model_%07d.ot" % step_no), hash_net, saver)
+
+        return loop.run(directory, starting_steps, steps, min_selfplay, min_reanalyze, steps_before_reanalyze, read_interval, sleep,
+                        max_wait, on_step)
+    finally:
+        saver.close()

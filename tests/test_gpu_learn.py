@@ -192,3 +192,110 @@ def test_closed_loop_learn_writes_models_that_selfplay_reloads(tmp_path):
     assert steps2 == produced // B and os.path.exists(os.path.join(d2, "model_%07d.ot" % steps2))
     assert not np.array_equal(fresh.tensor("policy.conv2d.weight"), w["policy.conv2d.weight"])
     assert np.array_equal(fresh.tensor("ube.linear.weight"), w["ube.linear.weight"])  # the UBE head is not trained there
+
+
+def test_native_learn_loop_buffers_sampling_and_augmentation(tmp_path):
+    """tz_learn_* (csrc/tz_host_learn.cpp): file tailing, forced uses, sampling without replacement, and the batch
+    tensors under a random symmetry — every row must be a symmetric image of one of the fed targets, with its policy
+    moved to the symmetric moves, the mask exactly the complement of the legal moves, value and UBE untouched."""
+    A = require_gpu()
+    from takzero_amd import augment as AU
+    from takzero_amd import formats as F
+    from takzero_amd import learn as L
+    from takzero_amd import weights as W
+    from test_learn_host import _targets
+
+    oracle = O.load()
+    n, B = 4, 64
+    targets = _targets(n, 96, 5)
+    lines = [F.format_target(n, *t) for t in targets]
+    path = tmp_path / "targets-selfplay.txt"
+    path.write_text("".join(lines[:80]) + "junk\n" + lines[80][:17])
+    trainer = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=1, batch=B).load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=2))
+    loop = L.NativeLearnLoop(trainer, 4, seed=1, forced_uses=(2, 2))
+    assert loop.feed(0, path) == 80 and loop.buffer_len(0) == 80 and loop.feed(0, path) == 0
+    with open(path, "a") as f:
+        f.write(lines[80][17:] + "".join(lines[81:]))
+    assert loop.feed(0, path) == 16 and loop.buffer_len(0) == 96
+    losses = loop.step(using_reanalyze=False, train_ube=True, augment=True)
+    assert all(np.isfinite(losses)) and loop.buffer_len(0) == 96          # 64 used once of two: all back
+    states, policy, mask, value, ube = loop.last_batch()
+    by_key = {}
+    for t in targets:   # every symmetric image of every fed target
+        parsed = F.parse_target(F.format_target(n, *t), n, 4)
+        for sym in range(8):
+            st = AU.augment_state(parsed[0], sym, n)
+            by_key.setdefault(A.state_to_tps(st) + "|%r|%r" % (float(parsed[3]), float(parsed[4])), []).append((parsed, sym))
+    seen = {}
+    for i in range(B):
+        key = A.state_to_tps(states[i]) + "|%r|%r" % (float(value[i]), float(ube[i]))
+        assert key in by_key, i
+        legal = O.possible_moves(oracle, O.TzState.from_buffer_copy(np.array([states[i]]).tobytes()))
+        assert sorted(legal) == sorted(np.nonzero(mask[i] == 0)[0].tolist())
+        ok = False
+        for parsed, sym in by_key[key]:   # a position that is its own mirror image matches under more than one symmetry
+            moved = AU.augment_moves(parsed[1], sym, n).astype(np.int64)
+            assert sorted(moved.tolist()) == sorted(legal)
+            ok = ok or np.array_equal(policy[i, moved], parsed[2])
+        assert ok, i
+        assert abs(float(policy[i].sum(dtype=np.float64)) - float(by_key[key][0][0][2].sum(dtype=np.float64))) < 1e-6
+        p0 = by_key[key][0][0]
+        ident = A.state_to_tps(p0[0]) + "|%r|%r" % (float(p0[3]), float(p0[4]))
+        seen[ident] = seen.get(ident, 0) + 1
+    have = {}
+    for t in targets:
+        p0 = F.parse_target(F.format_target(n, *t), n, 4)
+        ident = A.state_to_tps(p0[0]) + "|%r|%r" % (float(p0[3]), float(p0[4]))
+        have[ident] = have.get(ident, 0) + 1
+    assert sum(seen.values()) == B and all(c <= have[k] for k, c in seen.items())   # without replacement: no target drawn twice
+    loop.step(augment=True)                                                 # 64 uses of 192 left, held by 32..64 targets
+    left = loop.buffer_len(0)
+    assert 32 <= left <= 64
+    if left < B:                                                            # fewer targets than a batch: the caller has to wait
+        with pytest.raises(A.TakzeroError):
+            loop.step()
+    once = L.NativeLearnLoop(trainer, 4, seed=2, forced_uses=(1, 1))
+    assert once.feed(0, path) == 96
+    once.step()
+    assert once.buffer_len(0) == 32                                         # one use each: a drawn target is gone
+    with pytest.raises(A.TakzeroError):
+        once.step()
+
+
+def test_native_learn_main_loop_on_a_directory(tmp_path):
+    """run_learn_native: resume / pre-training / model files from Python host tools, buffers + batches + loop native."""
+    A = require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import learn as L
+    from takzero_amd import ot
+    from takzero_amd import runner as R
+    from takzero_amd import weights as W
+
+    try:
+        ot.build_writer()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    d, n, blocks, B = str(tmp_path), 4, 1, 64
+    w = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=21)
+    trainer = L.Trainer(arch=A.ARCH_TEST, n=n, blocks=blocks, batch=B).load_tensors(w)
+    dummy = A.BatchedMCTS(96, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 10)
+    net = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(w)
+    mcts = A.BatchedMCTS(96, n, 4, agent=net, node_capacity=1 << 13)
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    R.run_selfplay(d, mcts, 16, moves=40, seed=2, search="gumbel", sampled_actions=4, watch_model=False, native=True, max_wait=5)
+    produced = sum(1 for _ in open(os.path.join(d, "targets-selfplay.txt")))
+    logs = []
+    steps = L.run_learn_native(d, trainer, steps=7, seed=1, pre_train_mcts=dummy, min_selfplay=B, steps_before_reanalyze=10 ** 9,
+                               steps_per_save=2, steps_per_checkpoint=4, pre_training_steps=5, initial_targets=5 * B,
+                               read_interval=0.0, sleep=0.01, max_wait=20, log=logs.append)
+    assert steps == 12 and sum(1 for m in logs if m.startswith("step ")) == 7
+    names = sorted(os.listdir(d))
+    for want in ("model_0000000.ot", "model_0000005.ot", "model_0000008.ot", "model_0000012.ot", "model_latest.ot", "targets-initial.txt"):
+        assert want in names, names
+    sp_len, re_len = R.read_buffer_lengths(d)
+    assert re_len == 0 and 0 < sp_len <= produced
+    latest = ot.load_ot(os.path.join(d, "model_latest.ot"))
+    assert np.array_equal(latest["policy.conv2d.weight"], trainer.tensor("policy.conv2d.weight"))
+    assert not np.array_equal(latest["policy.conv2d.weight"], w["policy.conv2d.weight"])
+    with pytest.raises(TimeoutError):   # nothing left to learn from: the loop waits for targets, here until max_wait
+        L.run_learn_native(d, trainer, steps=10 ** 6, min_selfplay=10 ** 6, read_interval=0.0, sleep=0.01, max_wait=0.2)
