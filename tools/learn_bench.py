@@ -54,7 +54,9 @@ def main():
             f.write(F.format_targets(n, targets))
         loop_steps = 350
         stamps = []
-        L.run_learn(d, tr, steps=loop_steps, seed=1, pre_train_mcts=None, min_selfplay=10000,
+        run = L.run_learn_native if "--native" in sys.argv else L.run_learn
+        line["loop_driver"] = "native" if "--native" in sys.argv else "python"
+        run(d, tr, steps=loop_steps, seed=1, pre_train_mcts=None, min_selfplay=10000,
                     steps_before_reanalyze=10 ** 9, read_interval=10.0, sleep=0.01, max_wait=60,
                     log=lambda msg: stamps.append(time.perf_counter()))
         dt_loop = (stamps[-1] - stamps[49]) / (len(stamps) - 50)   # steady state: after start-up saves and the first read
