@@ -298,15 +298,17 @@ int tz_learn_run(tz_learn* l, const char* directory, int64_t starting_steps, int
     int64_t model_steps = starting_steps, done = 0;
     std::future<int> pending;
     float pending_losses[3] = {0, 0, 0};
+    std::string pending_error;   // the error text is per thread: carry it over from the worker
     int64_t pending_step = 0;
     int slot = 0, pending_slot = 0, rc = TZ_OK;
     auto finish = [&]() -> int {
         if (!pending.valid()) return TZ_OK;
         int r = pending.get();
-        if (!r) l->steps_done++;
-        if (!r && on_step)
-            r = on_step(user, pending_step, pending_losses, l->tensors[pending_slot].states.data(), l->B) ? TZ_ESTATE : TZ_OK;
-        return r;
+        if (r) return tz_fail(r, pending_error);
+        l->steps_done++;
+        if (on_step && on_step(user, pending_step, pending_losses, l->tensors[pending_slot].states.data(), l->B))
+            return tz_fail(TZ_ESTATE, "tz_learn_run: the on_step callback asked to stop");
+        return TZ_OK;
     };
     while (steps < 0 || done < steps) {
         model_steps++;
@@ -338,7 +340,11 @@ int tz_learn_run(tz_learn* l, const char* directory, int64_t starting_steps, int
         pending_step = model_steps;
         pending_slot = slot;
         const int use = slot;
-        pending = std::async(std::launch::async, [l, use, &pending_losses]() { return step_batch(l, use, 1, pending_losses); });
+        pending = std::async(std::launch::async, [l, use, &pending_losses, &pending_error]() {
+            const int r = step_batch(l, use, 1, pending_losses);
+            if (r) pending_error = tz_last_error();
+            return r;
+        });
         slot ^= 1;
         done++;
     }

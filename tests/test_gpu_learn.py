@@ -299,3 +299,15 @@ def test_native_learn_main_loop_on_a_directory(tmp_path):
     assert not np.array_equal(latest["policy.conv2d.weight"], w["policy.conv2d.weight"])
     with pytest.raises(TimeoutError):   # nothing left to learn from: the loop waits for targets, here until max_wait
         L.run_learn_native(d, trainer, steps=10 ** 6, min_selfplay=10 ** 6, read_interval=0.0, sleep=0.01, max_wait=0.2)
+
+    class Stop(Exception):
+        pass
+
+    def raising(step_no, losses, states):
+        if step_no == steps + 2:
+            raise Stop()
+
+    loop = L.NativeLearnLoop(trainer, 4, seed=3)
+    with pytest.raises(Stop):   # an exception in the step callback ends the native loop and surfaces here
+        loop.run(d, steps, 50, min_selfplay=B, steps_before_reanalyze=10 ** 9, read_interval=0.0, sleep=0.01, max_wait=10, on_step=raising)
+    loop.close()

@@ -4,14 +4,18 @@ cd "$(dirname "$0")/.."
 D=$(mktemp -d)
 S=${1:-240}
 mkdir -p gpurun_out
-python tools/concurrent_demo.py learn "$D" $S 2>&1 | tee -a gpurun_out/concurrent.log &
-python tools/concurrent_demo.py selfplay "$D" $S 2>&1 | tee -a gpurun_out/concurrent.log &
-python tools/concurrent_demo.py reanalyze "$D" $S 2>&1 | tee -a gpurun_out/concurrent.log &
+LOG=gpurun_out/concurrent.log
+PIDS=()
+for role in learn selfplay reanalyze; do
+    python tools/concurrent_demo.py $role "$D" $S >> $LOG 2>&1 &
+    PIDS+=($!)
+done
+alive() { for p in "${PIDS[@]}"; do kill -0 $p 2>/dev/null && return 0; done; return 1; }
 for i in $(seq 1 $((S / 20 + 3))); do   # progress: what the three processes have put into the directory so far
     sleep 20
-    echo "[watch] selfplay targets $(wc -l < "$D/targets-selfplay.txt" 2>/dev/null || echo 0) replays $(wc -l < "$D/replays.txt" 2>/dev/null || echo 0) reanalyze targets $(wc -l < "$D/targets-reanalyze.txt" 2>/dev/null || echo 0) buffer_lengths $(cat "$D/buffer_lengths.txt" 2>/dev/null) models $(ls "$D" | grep -c "\.ot$")" | tee -a gpurun_out/concurrent.log
-    if ! pgrep -P $$ python > /dev/null; then break; fi
+    echo "[watch] selfplay targets $(wc -l < "$D/targets-selfplay.txt" 2>/dev/null || echo 0) replays $(wc -l < "$D/replays.txt" 2>/dev/null || echo 0) reanalyze targets $(wc -l < "$D/targets-reanalyze.txt" 2>/dev/null || echo 0) buffer_lengths $(cat "$D/buffer_lengths.txt" 2>/dev/null) models $(ls "$D" | grep -c "\.ot$")" | tee -a $LOG
+    alive || break
 done
-pkill -P $$ python 2>/dev/null || true   # only this script's own children
+for p in "${PIDS[@]}"; do kill $p 2>/dev/null || true; done   # exactly the three processes started above
 wait
-ls -la "$D" | tee -a gpurun_out/concurrent.log
+ls -la "$D" | tee -a $LOG
