@@ -960,12 +960,183 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* 
     }
 }
 
-template <int NB, int P, int RNP, typename ET>
+// ---------------------------------------------------------------------------------------------
+// Row order of the LDS image.  A 3x3 tap whose source square is off the board multiplies a zero row: on 5x5 that is 56 of
+// the 225 (square, tap) pairs.  An MFMA covers 16 rows, so the zeros can only be skipped 16 rows at a time: with PERM the
+// rows of a workgroup are ordered square-major — row = tile*16 + slot*P + board, where tile*PPT + slot = the square's
+// place in an order that puts squares of the same board edge into the same tile — so that a row tile holds PPT = 16/P
+// squares of all P boards and, for an edge tile, three of the nine taps are off the board for every row of it.  Those
+// (tap, tile) pairs are left out of the k-loop at compile time (`tap_tile_mask`): 26 of 117 on 5x5 (P = 8), 12 of 81 on
+// 6x6 (P = 4), 32 of 81 on 3x3 (P = 16); what is skipped adds exact zeros, the result is bit-identical.
+// Without PERM rows are board-major (row = board*NN + square), the order of the activations in global memory.
+template <int NB, int P, bool PERM>
+struct RowMap {
+    static constexpr int NN = NB * NB;
+    static constexpr int PPT = PERM ? 16 / P : 1;
+    static constexpr int SLOTS = PERM ? (NN + PPT - 1) / PPT * PPT : NN;
+    static constexpr int RT = PERM ? SLOTS / PPT : (P * NN + 15) / 16;
+    // the square at place k of the order (or -1: padding)
+    __host__ __device__ static constexpr int square_at(int k) {
+        if (k >= NN) return -1;
+        if (PERM && NB == 5) {  // pairs along the top, left, bottom and right edges (3 taps each), one edge square left over with
+                                // the interior, and a corner alone in the half-empty last tile (5 taps): 26 of 117 pairs skipped
+            constexpr int T[25] = {1, 2, 3, 4, 5, 10, 15, 20, 21, 22, 23, 24, 9, 14, 19, 6, 7, 8, 11, 12, 13, 16, 17, 18, 0};
+            return T[k];
+        }
+        if (PERM && NB == 6) {  // fours: the edges without corners, the corners, interior
+            constexpr int T[36] = {1, 2, 3, 4, 6, 12, 18, 24, 31, 32, 33, 34, 11, 17, 23, 29, 0, 5, 30, 35,
+                                   7, 8, 9, 10, 13, 14, 15, 16, 19, 20, 21, 22, 25, 26, 27, 28};
+            return T[k];
+        }
+        return k;
+    }
+    __host__ __device__ static constexpr int place_of(int square) {
+        for (int k = 0; k < NN; k++)
+            if (square_at(k) == square) return k;
+        return -1;
+    }
+    __host__ __device__ static constexpr int row_of(int board, int square) {
+        if (!PERM) return board * NN + square;
+        const int k = place_of(square);
+        return (k / PPT) * 16 + (k % PPT) * P + board;
+    }
+    // board and square of an image row; square = -1 for padding rows
+    __host__ __device__ static constexpr void decode(int row, int& board, int& square) {
+        if (!PERM) {
+            board = row / NN;
+            square = board < P ? row % NN : -1;
+            return;
+        }
+        const int i = row % 16;
+        board = i % P;
+        square = square_at((row / 16) * PPT + i / P);
+    }
+    // bit rt of the mask: row tile rt has at least one row whose source square under `tap` is on the board
+    __host__ __device__ static constexpr unsigned tap_tile_mask(int tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        unsigned m = 0;
+        for (int row = 0; row < RT * 16; row++) {
+            int board = 0, sq = -1;
+            decode(row, board, sq);
+            if (sq < 0) continue;
+            const int y = sq / NB + dy, x = sq % NB + dx;
+            if (y >= 0 && y < NB && x >= 0 && x < NB) m |= 1u << (row / 16);
+        }
+        return m;
+    }
+};
+
+// tap table entries of a lane under a row map (the general form of tap_bases_rc)
+template <int NB, int P, bool PERM, int LAYOUT>
+__device__ __forceinline__ void tap_bases_map(int tap, int lr, int q, int zrow, int (&abase)[RowMap<NB, P, PERM>::RT]) {
+    typedef RowMap<NB, P, PERM> RM;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int rt = 0; rt < RM::RT; rt++) {
+        const int r = rt * 16 + lr;
+        int board = 0, sq = -1;
+        RM::decode(r, board, sq);
+        const int y = sq / NB + dy, x = sq % NB + dx;
+        const bool ok = sq >= 0 && y >= 0 && y < NB && x >= 0 && x < NB;
+        // an off-board source reads the zero row with the lane's own row phase: the same LDS slot pattern as on the board
+        abase[rt] = LdsImg<LAYOUT>::read_base(ok, ok ? RM::row_of(board, y * NB + x) : r, q, zrow);
+    }
+}
+
+template <int N>
+struct IntC {
+    static constexpr int value = N;
+};
+
+// k_loop_256 with the tap loop unrolled and the all-zero (tap, row tile) pairs of the row map left out
+template <int NB, int P, int RNX, int PLANE, typename ET, typename WL>
+__device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const int* tap_table, int lane,
+                                                f32x4 (&acc)[RowMap<NB, P, true>::RT][RNX], WL wl) {
+    typedef typename Elem<ET>::x8 ex8;
+    typedef RowMap<NB, P, true> RM;
+    constexpr int TAPS = 9, RT = RM::RT;
+    ex8 bq[4][RNX];
+#pragma unroll
+    for (int j = 0; j < RNX; j++) {
+        bq[0][j] = wl(0, 0, j);
+        bq[1][j] = wl(0, 1, j);
+    }
+    int abase[RT];
+    ex8 av[RT];
+    {
+        constexpr unsigned M0 = RM::tap_tile_mask(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            if ((M0 >> rt) & 1) abase[rt] = tap_table[rt * 64 + lane];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            if ((M0 >> rt) & 1) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+    }
+    auto one_tap = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr unsigned NOW = RM::tap_tile_mask(tap);
+        constexpr unsigned NEXT = tap + 1 < TAPS ? RM::tap_tile_mask(tap + 1 < TAPS ? tap + 1 : tap) : 0u;
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            if (kc + 2 < 8) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
+            } else if (tap + 1 < TAPS) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc == 7) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    if ((NEXT >> rt) & 1) abase[rt] = tap_table[((tap + 1) * RT + rt) * 64 + lane];
+            }
+            if (kc == 4) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    if ((NOW >> rt) & 1) {
+                        abase[rt] += 4 * PLANE;
+                        asm volatile("" : "+v"(abase[rt]));
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                if ((NOW >> rt) & 1) {
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
+                }
+                if (kc < 7) {
+                    if ((NOW >> rt) & 1) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
+                } else if ((NEXT >> rt) & 1) {
+                    av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                }
+            }
+            // the issue order of k_loop_256: the MFMAs of a row tile, then the ds_read that refills its fragment
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                if ((NOW >> rt) & 1) __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
+                if (kc < 7 ? ((NOW >> rt) & 1) : ((NEXT >> rt) & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+    one_tap(IntC<0>{});
+    one_tap(IntC<1>{});
+    one_tap(IntC<2>{});
+    one_tap(IntC<3>{});
+    one_tap(IntC<4>{});
+    one_tap(IntC<5>{});
+    one_tap(IntC<6>{});
+    one_tap(IntC<7>{});
+    one_tap(IntC<8>{});
+}
+
+template <int NB, int P, int RNP, typename ET, bool PERM = false>
 __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
     constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
-    constexpr int NN = NB * NB, ROWS = P * NN, RT = (ROWS + 15) / 16, LROWS = RT * 16 + 8, ZROW = RT * 16;
+    typedef RowMap<NB, P, PERM> RM;
+    constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
     constexpr int LAYER_FRAGS = TAPS * 8 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -977,19 +1148,20 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, lr = lane & 15;
-    const int valid_rows = min(ROWS, (count - pos0) * NN);
+    const int valid_boards = min(P, count - pos0);
     const size_t m0 = (size_t)pos0 * NN;
     const int ct0 = wave * RN;
     const int lane16 = lane * 16;
 
     // ---- game_repr into planes 0..kc_in-1; zero rows of every plane
     for (int row = tid; row < LROWS; row += NT) {
-        const bool ok = row < valid_rows;
+        int board = 0, px = -1;
+        if (row < RT * 16) RM::decode(row, board, px);
+        const bool ok = px >= 0 && board < valid_boards;
         const tz_state* s = nullptr;
-        int px = 0, fd = 0;
+        int fd = 0;
         if (ok) {
-            const int pos = pos0 + row / NN;
-            px = row % NN;
+            const int pos = pos0 + board;
             s = a.states + (a.game_index ? a.game_index[pos] : pos);
             fd = state_flat_diff<NB>(s);
         }
@@ -1010,7 +1182,8 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     if (wave == 7) {  // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier)
         for (int tap = 0; tap < TAPS; tap++) {
             int tb[RT];
-            tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
+            if constexpr (PERM) tap_bases_map<NB, P, true, LAYOUT>(tap, lr, q, ZROW, tb);
+            else tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = tb[rt];
         }
@@ -1070,10 +1243,12 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             }
         }
         __syncthreads();
-        k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, acc, [&](int tap, int kc, int j) -> ex8 {
+        auto wl = [&](int tap, int kc, int j) -> ex8 {
             const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
             return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
-        });
+        };
+        if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET>(lds, tap_table, lane, acc, wl);
+        else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, acc, wl);
         __syncthreads();
         const bool to_second = (layer & 1) == 0;
 #pragma unroll
@@ -1109,7 +1284,8 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         const float* lu = lv + NN;
         const float bv = lu[NN], bu = lu[NN + 1], lbv = lu[NN + 2], lbu = lu[NN + 3];
         const int hplane = lane >> 3, hpiece = (lane & 7) >> 1, hhalf = lane & 1;  // channels 4*lane .. 4*lane+3
-        for (int row = wave; row < ROWS; row += 8) {
+        constexpr int HROWS = PERM ? RT * 16 : ROWS;
+        for (int row = wave; row < HROWS; row += 8) {
             const ex4 xv = *reinterpret_cast<const ex4*>(lds + hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8);
             float dv = 0.f, du = 0.f;
 #pragma unroll
@@ -1134,8 +1310,9 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             if (pos0 + pos >= count) break;
             float sv = 0.f, su = 0.f;
             for (int px = lane; px < NN; px += 64) {
-                sv += hscratch[pos * NN + px] * lv[px];
-                su += hscratch[RT * 16 + pos * NN + px] * lu[px];
+                const int hr = RM::row_of(pos, px);
+                sv += hscratch[hr] * lv[px];
+                su += hscratch[RT * 16 + hr] * lu[px];
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
@@ -1168,8 +1345,10 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             const int cbase = (ctp + j) * 16 + q * 4;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                const int r = rt * 16 + lr;
-                if (r < valid_rows) *reinterpret_cast<f32x4*>(a.policy_out + (m0 + r) * a.pol_stride + cbase) = pacc[rt][j];
+                int board = 0, sq = -1;
+                RM::decode(rt * 16 + lr, board, sq);
+                if (sq >= 0 && board < valid_boards)
+                    *reinterpret_cast<f32x4*>(a.policy_out + (m0 + board * NN + sq) * a.pol_stride + cbase) = pacc[rt][j];
             }
         }
     }
@@ -1846,11 +2025,11 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET>
+template <int NB, int RNP, typename ET, bool PERM>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
-    constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
+    constexpr int P = ppt_for(NB), RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
-    auto kern = net_mfma_kernel<NB, P, RNP, ET>;
+    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM>;
     static bool attr_set = false;
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1862,13 +2041,25 @@ int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     return TZ_OK;
 }
 
+// TZ_NET_ROWS=board selects the board-major row order without tap skipping (A/B; the default is the square-major order
+// with the all-zero (tap, row tile) pairs skipped wherever 16 % boards-per-workgroup == 0: 3x3, 5x5, 6x6)
+bool net_square_major() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TZ_NET_ROWS");
+        v = (e && !strcmp(e, "board")) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <typename ET>
 int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t st) {
+    const bool sq = net_square_major();
     switch (net->n) {
-        case 3: return launch_net<3, 1, ET>(a, max_positions, st);
-        case 4: return launch_net<4, 1, ET>(a, max_positions, st);
-        case 5: return launch_net<5, 1, ET>(a, max_positions, st);
-        case 6: return launch_net<6, 2, ET>(a, max_positions, st);
+        case 3: return sq ? launch_net<3, 1, ET, true>(a, max_positions, st) : launch_net<3, 1, ET, false>(a, max_positions, st);
+        case 4: return launch_net<4, 1, ET, false>(a, max_positions, st);
+        case 5: return sq ? launch_net<5, 1, ET, true>(a, max_positions, st) : launch_net<5, 1, ET, false>(a, max_positions, st);
+        case 6: return sq ? launch_net<6, 2, ET, true>(a, max_positions, st) : launch_net<6, 2, ET, false>(a, max_positions, st);
     }
     return tz_fail(TZ_EINVAL, "net: unsupported board size");
 }

@@ -1,0 +1,64 @@
+"""A/B of the net kernel's two row orders (TZ_NET_ROWS=board vs the default square-major order with zero-tap skipping):
+runs itself once per order in a child process, compares the raw outputs bit for bit.
+  python tools/net_rows_ab.py [n ...]"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(n, out):
+    import takzero_amd.api as A
+    from takzero_amd import weights as W
+
+    arch = {3: A.ARCH_TEST, 4: A.ARCH_TEST, 5: A.ARCH_NET5, 6: A.ARCH_NET6_SIMHASH}[n]
+    res = {}
+    for prec, pname in ((A.PREC_BF16, "bf16"), (A.PREC_F16, "f16")):
+        if arch == A.ARCH_TEST:
+            net = A.Net(arch=arch, n=n, blocks=3, precision=prec).load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=3, seed=5))
+        else:
+            net = A.Net.new(arch=arch, seed=5, precision=prec)
+        for count in (1, 7, 16, 333):   # ragged: counts that are not multiples of the boards per workgroup
+            dummy = A.BatchedMCTS(count, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 8)
+            rng = np.random.default_rng(count)
+            dummy.new_openings(rng.integers(0, 16, count))
+            for _ in range(6):      # a few random plies so that stacks, walls and capstones appear
+                dummy.simulate(np.zeros(count, np.float32), 4)
+                dummy.step(dummy.select_best_actions())
+                dummy.restart_terminal_envs(rng.integers(0, 16, count))
+            states = dummy.get_positions()
+            raw = net.forward_raw(states)
+            for k, v in zip(("policy", "value", "ube"), raw):
+                res["%s_%d_%s" % (pname, count, k)] = np.asarray(v)
+    np.savez(out, **res)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child(int(sys.argv[2]), sys.argv[3])
+    sizes = [int(a) for a in sys.argv[1:]] or [3, 5, 6]
+    bad = 0
+    for n in sizes:
+        outs = []
+        for rows in ("board", "square"):
+            out = "/tmp/net_rows_%s_%d.npz" % (rows, n)
+            env = dict(os.environ, TZ_NET_ROWS=rows)
+            subprocess.run([sys.executable, __file__, "--child", str(n), out], check=True, env=env)
+            outs.append(np.load(out))
+        for k in outs[0].files:
+            same = np.array_equal(outs[0][k].view(np.uint8), outs[1][k].view(np.uint8))
+            if not same:
+                bad += 1
+                d = np.abs(outs[0][k].astype(np.float64) - outs[1][k].astype(np.float64))
+                print("n=%d %s differs: max abs %.3g" % (n, k, np.nanmax(d)))
+        print("n=%d: %d arrays compared" % (n, len(outs[0].files)), flush=True)
+    print("BIT-IDENTICAL" if not bad else "%d arrays differ" % bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
