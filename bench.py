@@ -42,6 +42,13 @@ FLOP_PER_LAUNCH_POS = {0: CONV_FLOP_PER_POSITION,
 KERNEL_NAME = {0: "conv_mfma_kernel<5,8,2,9,false,0,true,8,1> (one 3x3 256->256 conv)",
                1: "tower_mfma_kernel<5,8> (20 residual blocks = 40 3x3 256->256 convs, one persistent launch)",
                2: "net_mfma_kernel<5,8,1> (game_repr + first conv + 20 residual blocks + policy conv + value/UBE heads, one persistent launch)"}[FUSED_MODE]
+# Of those FLOPs the net kernel does not issue the ones that multiply zero padding: with its square-major row order
+# (csrc/tz_nn.hip RowMap) 26 of the 117 (tap, 16-row tile) pairs of a tower conv are all padding on 5x5 and are
+# left out at compile time.  Issued MFMA FLOPs per position per launch (incl. the 208-for-200 row padding), for the
+# `issued` figures beside the algorithmic ones:
+SQUARE_MAJOR = os.environ.get("TZ_NET_ROWS", "square") != "board"
+TOWER_TILE_TAPS = (91 if SQUARE_MAJOR else 117, 117)
+ISSUED_FLOP_PER_LAUNCH_POS = (2 * 16 * 256 * 32 * (9 * 13 * 2 + TOWER_LAYERS * TOWER_TILE_TAPS[0] * 8 + 9 * 13 * 8 * 0.5)) / 8.0
 FUSED_TOWER = FUSED_MODE >= 1
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 
@@ -243,6 +250,10 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "kernel": KERNEL_NAME,
+                               "rows": "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS
+                               if FUSED_MODE == 2 else "board-major",
+                               "issued_tflops": (ISSUED_FLOP_PER_LAUNCH_POS * per_launch_positions / (avg_ms * 1e-3) / 1e12
+                                                 if FUSED_MODE == 2 else None),
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),

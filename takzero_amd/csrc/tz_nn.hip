@@ -983,9 +983,12 @@ struct RowMap {
             constexpr int T[25] = {1, 2, 3, 4, 5, 10, 15, 20, 21, 22, 23, 24, 9, 14, 19, 6, 7, 8, 11, 12, 13, 16, 17, 18, 0};
             return T[k];
         }
-        if (PERM && NB == 6) {  // fours: the edges without corners, the corners, interior
-            constexpr int T[36] = {1, 2, 3, 4, 6, 12, 18, 24, 31, 32, 33, 34, 11, 17, 23, 29, 0, 5, 30, 35,
-                                   7, 8, 9, 10, 13, 14, 15, 16, 19, 20, 21, 22, 25, 26, 27, 28};
+        if (PERM && NB == 6) {  // fours: the edges without corners, the corners, interior.  Inside a four the places alternate
+                                // with the checkerboard colour of the square ((x + y) & 1 == place & 1): the 16-B piece
+                                // rotation of the LDS image follows bit 2 of the row = bit 0 of the place, and any tap moves
+                                // both squares of a place pair to the same colour change, so the pair never shares a bank
+            constexpr int T[36] = {2, 1, 4, 3, 12, 6, 24, 18, 31, 32, 33, 34, 11, 17, 23, 29, 0, 5, 35, 30,
+                                   7, 8, 9, 10, 14, 13, 16, 15, 19, 20, 21, 22, 26, 25, 28, 27};
             return T[k];
         }
         return k;
@@ -1038,8 +1041,10 @@ __device__ __forceinline__ void tap_bases_map(int tap, int lr, int q, int zrow, 
         RM::decode(r, board, sq);
         const int y = sq / NB + dy, x = sq % NB + dx;
         const bool ok = sq >= 0 && y >= 0 && y < NB && x >= 0 && x < NB;
-        // an off-board source reads the zero row with the lane's own row phase: the same LDS slot pattern as on the board
-        abase[rt] = LdsImg<LAYOUT>::read_base(ok, ok ? RM::row_of(board, y * NB + x) : r, q, zrow);
+        // an off-board source reads the zero row with the row phase its on-board source would have had (P = 4: the colour
+        // of the source square, see square_at): the same LDS slot pattern as on the board
+        const int zr = (P == 4 && ((dy + dx) & 1)) ? r ^ 4 : r;
+        abase[rt] = LdsImg<LAYOUT>::read_base(ok, ok ? RM::row_of(board, y * NB + x) : zr, q, zrow);
     }
 }
 
