@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--games", type=int, default=GAMES)
-    ap.add_argument("--sims", type=int, default=SIMS)
+    ap.add_argument("--sims", type=int, default=None, help="simulations per move (default %d; 768 with --search gumbel, whose budget must be a multiple of k*log2 k)" % SIMS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--capacity", type=int, default=0)
@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16",
                     help="16-bit storage type of the MFMA path (same kernels, same rate; f16 is within 1e-3 of fp32)")
     args = ap.parse_args()
+    if args.sims is None:
+        args.sims = 768 if args.search == "gumbel" else SIMS
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started as plain `python bench.py --gpus N`: run the N ranks as a child torch.distributed.run job (nothing in
