@@ -193,3 +193,18 @@ def test_network_lifecycle_new_save_load_partial_clone(oracle, tmp_path):
     mixed.update({k: v for k, v in W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=5).items() if k.startswith("policy.")})
     d = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(mixed)
     assert all(np.array_equal(x, y) for x, y in zip(a.forward_raw(states), d.forward_raw(states)))
+
+
+@pytest.mark.gpu
+def test_square_major_row_order_is_bit_identical_to_board_major():
+    """The net kernel's square-major row order leaves out the (tap, row tile) pairs that only multiply zero padding
+    (csrc/tz_nn.hip RowMap): policy, value and UBE must equal, byte for byte, what the board-major kernel that issues every
+    pair produces (TZ_NET_ROWS=board) - 3x3 / 5x5 / 6x6 nets, bf16 and f16, batch sizes that leave partial workgroups."""
+    require_gpu()
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "net_rows_ab.py"), "3", "5", "6"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "BIT-IDENTICAL" in out.stdout, out.stdout + out.stderr
