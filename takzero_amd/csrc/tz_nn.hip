@@ -1029,6 +1029,36 @@ struct RowMap {
     }
 };
 
+// compile-time checks of the orders above: every square exactly once, and the number of (tap, tile) pairs left to issue
+template <int NB, int P, bool PERM>
+constexpr bool row_map_is_permutation() {
+    typedef RowMap<NB, P, PERM> RM;
+    for (int sq = 0; sq < NB * NB; sq++) {
+        int seen = 0;
+        for (int k = 0; k < NB * NB; k++) seen += RM::square_at(k) == sq;
+        if (seen != 1) return false;
+    }
+    for (int b = 0; b < P; b++)
+        for (int sq = 0; sq < NB * NB; sq++) {
+            int board = -1, back = -1;
+            RM::decode(RM::row_of(b, sq), board, back);
+            if (board != b || back != sq) return false;
+        }
+    return true;
+}
+template <int NB, int P, bool PERM>
+constexpr int row_map_pairs_issued() {
+    int n = 0;
+    for (int tap = 0; tap < 9; tap++)
+        for (unsigned m = RowMap<NB, P, PERM>::tap_tile_mask(tap); m; m >>= 1) n += m & 1;
+    return n;
+}
+static_assert(row_map_is_permutation<5, 8, true>() && row_map_is_permutation<6, 4, true>() && row_map_is_permutation<3, 16, true>() &&
+                  row_map_is_permutation<5, 8, false>() && row_map_is_permutation<4, 12, false>(),
+              "RowMap: row_of / decode must be inverse bijections");
+static_assert(row_map_pairs_issued<5, 8, true>() == 91 && row_map_pairs_issued<5, 8, false>() == 117, "5x5: 26 of 117 pairs skipped");
+static_assert(row_map_pairs_issued<6, 4, true>() == 69 && row_map_pairs_issued<3, 16, true>() == 49, "6x6: 12 of 81, 3x3: 32 of 81");
+
 // tap table entries of a lane under a row map (the general form of tap_bases_rc)
 template <int NB, int P, bool PERM, int LAYOUT>
 __device__ __forceinline__ void tap_bases_map(int tap, int lr, int q, int zrow, int (&abase)[RowMap<NB, P, PERM>::RT]) {
