@@ -2060,9 +2060,9 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET, bool PERM>
+template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB)>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
-    constexpr int P = ppt_for(NB), RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
+    constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
     auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM>;
     static bool attr_set = false;
@@ -2087,9 +2087,26 @@ bool net_square_major() {
     return v == 1;
 }
 
+// Boards per workgroup for small batches.  A workgroup takes the same time whether its image holds 1 board or 8 (it is
+// bound by its own stream of the 47 MB of weights or by its MFMAs, whichever is longer), so a batch that cannot fill the
+// 256 CUs with 8-board workgroups is spread over more, smaller ones: the Agent surface at the reference's batch of 128
+// (tz_net_eval) and small searches (puzzles, compete, tei-sized batches).  The result of a position does not depend on
+// the choice (same k order).  TZ_NET_P=full keeps the full-size workgroups (A/B).
+int net_small_p(int max_positions) {
+    static const bool full = getenv("TZ_NET_P") && !strcmp(getenv("TZ_NET_P"), "full");
+    if (full) return 0;
+    return max_positions <= 256 ? 1 : max_positions <= 512 ? 2 : max_positions <= 1024 ? 4 : 0;
+}
+
 template <typename ET>
 int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t st) {
     const bool sq = net_square_major();
+    const int small = net_small_p(max_positions);
+    if (net->n == 5 && small == 1) return launch_net<5, 1, ET, false, 1>(a, max_positions, st);
+    if (net->n == 5 && small == 2) return launch_net<5, 1, ET, false, 2>(a, max_positions, st);
+    if (net->n == 5 && small == 4) return launch_net<5, 1, ET, false, 4>(a, max_positions, st);
+    if (net->n == 6 && small == 1) return launch_net<6, 2, ET, false, 1>(a, max_positions, st);
+    if (net->n == 6 && small == 2) return launch_net<6, 2, ET, false, 2>(a, max_positions, st);
     switch (net->n) {
         case 3: return sq ? launch_net<3, 1, ET, true>(a, max_positions, st) : launch_net<3, 1, ET, false>(a, max_positions, st);
         case 4: return launch_net<4, 1, ET, false>(a, max_positions, st);

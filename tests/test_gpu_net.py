@@ -196,10 +196,11 @@ def test_network_lifecycle_new_save_load_partial_clone(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_square_major_row_order_is_bit_identical_to_board_major():
+def test_net_launch_forms_are_bit_identical():
     """The net kernel's square-major row order leaves out the (tap, row tile) pairs that only multiply zero padding
-    (csrc/tz_nn.hip RowMap): policy, value and UBE must equal, byte for byte, what the board-major kernel that issues every
-    pair produces (TZ_NET_ROWS=board) - 3x3 / 5x5 / 6x6 nets, bf16 and f16, batch sizes that leave partial workgroups."""
+    (csrc/tz_nn.hip RowMap), and small batches run on 1-, 2- or 4-board workgroups: policy, value and UBE must equal, byte
+    for byte, what the board-major kernel with full-size workgroups that issues every pair produces (TZ_NET_ROWS=board
+    TZ_NET_P=full) - 3x3 / 5x5 / 6x6 nets, bf16 and f16, batch sizes 1 .. 1030 that leave partial workgroups."""
     require_gpu()
     import subprocess
     import sys

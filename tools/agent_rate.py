@@ -19,10 +19,10 @@ states = mcts.get_positions()
 ch = mcts.root_children()
 info = mcts.root_info()
 acts = [ch["move_idx"][g, :info["n_children"][g]] for g in range(4096)]
-for B in (128, 4096):
+for B in (1, 8, 32, 128, 256, 512, 1024, 4096):
     net.policy_value_uncertainty(states[:B], acts[:B])
     t0 = time.perf_counter()
-    n = 10
+    n = 30 if B <= 1024 else 10
     for _ in range(n):
         net.policy_value_uncertainty(states[:B], acts[:B])
     dt = (time.perf_counter() - t0) / n

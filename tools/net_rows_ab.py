@@ -1,5 +1,7 @@
-"""A/B of the net kernel's two row orders (TZ_NET_ROWS=board vs the default square-major order with zero-tap skipping):
-runs itself once per order in a child process, compares the raw outputs bit for bit.
+"""A/B of the net kernel's launch forms: board-major rows with full-size workgroups (TZ_NET_ROWS=board TZ_NET_P=full: every
+(tap, row tile) pair issued) against the square-major order with zero-tap skipping, and against the default, which also
+spreads small batches over 1- and 2-board workgroups.  Runs itself once per form in a child process and compares the raw
+outputs bit for bit.
   python tools/net_rows_ab.py [n ...]"""
 import os
 import subprocess
@@ -22,7 +24,7 @@ def child(n, out):
             net = A.Net(arch=arch, n=n, blocks=3, precision=prec).load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=3, seed=5))
         else:
             net = A.Net.new(arch=arch, seed=5, precision=prec)
-        for count in (1, 7, 16, 333):   # ragged: counts that are not multiples of the boards per workgroup
+        for count in (1, 7, 16, 333, 515, 1030):   # ragged: counts that are not multiples of the boards per workgroup
             dummy = A.BatchedMCTS(count, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 8)
             rng = np.random.default_rng(count)
             dummy.new_openings(rng.integers(0, 16, count))
@@ -44,18 +46,23 @@ def main():
     bad = 0
     for n in sizes:
         outs = []
-        for rows in ("board", "square"):
-            out = "/tmp/net_rows_%s_%d.npz" % (rows, n)
-            env = dict(os.environ, TZ_NET_ROWS=rows)
+        forms = (("board-major, full workgroups", {"TZ_NET_ROWS": "board", "TZ_NET_P": "full"}),
+                 ("square-major, full workgroups", {"TZ_NET_ROWS": "square", "TZ_NET_P": "full"}),
+                 ("default", {}))
+        for i, (name, extra) in enumerate(forms):
+            out = "/tmp/net_rows_%d_%d.npz" % (i, n)
+            env = {k: v for k, v in os.environ.items() if k not in ("TZ_NET_ROWS", "TZ_NET_P")}
+            env.update(extra)
             subprocess.run([sys.executable, __file__, "--child", str(n), out], check=True, env=env)
             outs.append(np.load(out))
-        for k in outs[0].files:
-            same = np.array_equal(outs[0][k].view(np.uint8), outs[1][k].view(np.uint8))
-            if not same:
-                bad += 1
-                d = np.abs(outs[0][k].astype(np.float64) - outs[1][k].astype(np.float64))
-                print("n=%d %s differs: max abs %.3g" % (n, k, np.nanmax(d)))
-        print("n=%d: %d arrays compared" % (n, len(outs[0].files)), flush=True)
+        for i in (1, 2):
+            for k in outs[0].files:
+                same = np.array_equal(outs[0][k].view(np.uint8), outs[i][k].view(np.uint8))
+                if not same:
+                    bad += 1
+                    d = np.abs(outs[0][k].astype(np.float64) - outs[i][k].astype(np.float64))
+                    print("n=%d %s: %s differs from %s: max abs %.3g" % (n, k, forms[i][0], forms[0][0], np.nanmax(d)))
+        print("n=%d: %d arrays x 2 forms compared" % (n, len(outs[0].files)), flush=True)
     print("BIT-IDENTICAL" if not bad else "%d arrays differ" % bad)
     return 1 if bad else 0
 
