@@ -38,6 +38,11 @@ struct tz_net {
     void *rnd_in = nullptr, *rnd_h1 = nullptr, *rnd_h2 = nullptr;  // RND activations
     float* rnd_out = nullptr;                                       // [2][max_batch][512]
     hipStream_t stream = nullptr;
+    // staging of the Agent surface (tz_net_eval): one pinned host buffer and one device buffer, grown on demand, so that
+    // a call is one host-to-device copy, the kernels, one device-to-host copy
+    void* eval_host = nullptr;
+    void* eval_dev = nullptr;
+    size_t eval_bytes = 0;
     // profiling of the dominant kernel (residual-tower conv)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;

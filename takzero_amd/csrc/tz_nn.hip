@@ -902,15 +902,19 @@ struct NetArgs {
 // tap_table[tap][rt][lane]: the lane's fragment base address for row tile rt under tap `tap` (tap_bases_rc, computed once
 // per kernel into LDS: a tap boundary then costs RT ds_read_b32 instead of ~10 VALU instructions per row tile —
 // measured on the tower twin, `tools/tower_bench.py 128 4224`: 3.376 -> 3.065 ms)
-template <int NB, int RT, int RNX, int ROWS, int ZROW, int PLANE, typename ET, typename WL>
+// PD = weight prefetch distance in k-steps: 2 (ring of 4) for the full-size workgroups, whose k-steps are 26 MFMAs long;
+// 6 (ring of 8) for the 1- and 2-board workgroups of small batches, whose k-steps are 4-8 MFMAs and which would
+// otherwise wait for L2 at every step.
+template <int NB, int RT, int RNX, int ROWS, int ZROW, int PLANE, typename ET, int PD = 2, typename WL>
 __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&acc)[RT][RNX], WL wl) {
     typedef typename Elem<ET>::x8 ex8;
-    constexpr int TAPS = 9;
-    ex8 bq[4][RNX];
+    constexpr int TAPS = 9, RING = PD <= 2 ? 4 : 8;
+    static_assert(PD < RING && PD <= 8, "prefetch distance");
+    ex8 bq[RING][RNX];
 #pragma unroll
     for (int j = 0; j < RNX; j++) {
-        bq[0][j] = wl(0, 0, j);
-        bq[1][j] = wl(0, 1, j);
+#pragma unroll
+        for (int d = 0; d < PD; d++) bq[d][j] = wl(0, d, j);
     }
     int abase[RT];
 #pragma unroll
@@ -921,12 +925,12 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* 
     for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
         for (int kc = 0; kc < 8; kc++) {
-            if (kc + 2 < 8) {
+            if (kc + PD < 8) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
+                for (int j = 0; j < RNX; j++) bq[(kc + PD) & (RING - 1)][j] = wl(tap, kc + PD, j);
             } else if (tap + 1 < TAPS) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+                for (int j = 0; j < RNX; j++) bq[(kc + PD) & (RING - 1)][j] = wl(tap + 1, kc + PD - 8, j);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kc == 7) {
@@ -944,7 +948,7 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* 
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
+                for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & (RING - 1)][j], av[rt], acc[rt][j]);
                 if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
                 else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
             }
@@ -1283,7 +1287,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
         };
         if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET>(lds, tap_table, lane, acc, wl);
-        else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, acc, wl);
+        else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
         __syncthreads();
         const bool to_second = (layer & 1) == 0;
 #pragma unroll
@@ -1584,6 +1588,23 @@ __global__ void bitset_set_kernel(uint32_t* bitset, const uint32_t* index, int n
 __global__ void gather_kernel(const float* policy, int nn, int stride, const uint16_t* legal, const int32_t* cnt,
                               int amax, int batch, float* out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * amax) return;
+    const int b = idx / amax, j = idx % amax;
+    float v = 0.f;
+    if (j < cnt[b]) {
+        const int a = legal[idx];
+        v = policy[((size_t)b * nn + a % nn) * stride + a / nn];
+    }
+    out[idx] = v;
+}
+// the same for the Agent surface, plus value and variance into the same output buffer (one copy back)
+__global__ void eval_pack_kernel(const float* policy, int nn, int stride, const uint16_t* legal, const int32_t* cnt, int amax, int batch,
+                                 const float* value, const float* variance, float* out, float* value_out, float* variance_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < batch) {
+        value_out[idx] = value[idx];
+        variance_out[idx] = variance[idx];
+    }
     if (idx >= batch * amax) return;
     const int b = idx / amax, j = idx % amax;
     float v = 0.f;
@@ -2690,6 +2711,8 @@ int tz_net_destroy(tz_net* net) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    if (net->eval_dev) (void)hipFree(net->eval_dev);
+    if (net->eval_host) (void)hipHostFree(net->eval_host);
     if (net->stream) (void)hipStreamDestroy(net->stream);
     delete net;
     return TZ_OK;
@@ -2716,42 +2739,50 @@ int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* 
             if (legal_idx[(size_t)b * amax + j] >= net->pol_ch * net->nn)
                 return tz_fail(TZ_EINVAL, "tz_net_eval: move index out of range");
     }
-    tz_state* dstates = nullptr;
-    int rc = net_upload_states(net, batch, states, &dstates);
+    // one staging buffer on each side: [states | legal_idx | legal_count] in, [logits | value | variance] out
+    TZ_HIP(hipSetDevice(net->device));
+    int rc = tz_net_ensure_batch(net, batch);
     if (rc) return rc;
-    uint16_t* dlegal = nullptr;
-    int32_t* dcnt = nullptr;
-    float* dlog = nullptr;
-    hipStream_t st = net->stream;
-    auto cleanup = [&]() {
-        (void)hipFree(dstates);
-        if (dlegal) (void)hipFree(dlegal);
-        if (dcnt) (void)hipFree(dcnt);
-        if (dlog) (void)hipFree(dlog);
-    };
-    NetOut o;
-    rc = tz_net_forward_device(net, dstates, nullptr, nullptr, batch, batch, st, &o);
-    if (rc) {
-        cleanup();
-        return rc;
-    }
     const size_t cells = (size_t)batch * amax;
-    if (hipMalloc(&dlegal, cells * 2) != hipSuccess || hipMalloc(&dcnt, batch * 4) != hipSuccess ||
-        hipMalloc(&dlog, cells * 4) != hipSuccess) {
-        cleanup();
-        return tz_fail(TZ_ENOMEM, "tz_net_eval: device allocation failed");
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_states = 0, o_legal = up16(o_states + (size_t)batch * sizeof(tz_state)), o_cnt = up16(o_legal + cells * 2),
+                 in_bytes = up16(o_cnt + (size_t)batch * 4);
+    const size_t o_log = in_bytes, o_val = up16(o_log + cells * 4), o_var = up16(o_val + (size_t)batch * 4),
+                 total = up16(o_var + (size_t)batch * 4);
+    if (total > net->eval_bytes) {
+        TZ_HIP(hipStreamSynchronize(net->stream));
+        if (net->eval_dev) (void)hipFree(net->eval_dev);
+        if (net->eval_host) (void)hipHostFree(net->eval_host);
+        net->eval_dev = net->eval_host = nullptr;
+        net->eval_bytes = 0;
+        const size_t want = total + total / 2;
+        if (hipMalloc(&net->eval_dev, want) != hipSuccess || hipHostMalloc(&net->eval_host, want, hipHostMallocDefault) != hipSuccess) {
+            if (net->eval_dev) (void)hipFree(net->eval_dev);
+            net->eval_dev = nullptr;
+            return tz_fail(TZ_ENOMEM, "tz_net_eval: staging allocation failed");
+        }
+        net->eval_bytes = want;
     }
-    hipError_t e = hipMemcpyAsync(dlegal, legal_idx, cells * 2, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(dcnt, legal_count, batch * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        gather_kernel<<<(int)((cells + 255) / 256), 256, 0, st>>>(o.policy, net->nn, o.policy_stride, dlegal, dcnt, amax, batch, dlog);
-        e = hipMemcpyAsync(logits_out, dlog, cells * 4, hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(value_out, o.value, batch * 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(variance_out, o.variance, batch * 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    cleanup();
-    if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tz_net_eval: ") + hipGetErrorString(e));
+    char* host = static_cast<char*>(net->eval_host);
+    char* dev = static_cast<char*>(net->eval_dev);
+    memcpy(host + o_states, states, (size_t)batch * sizeof(tz_state));
+    memcpy(host + o_legal, legal_idx, cells * 2);
+    memcpy(host + o_cnt, legal_count, (size_t)batch * 4);
+    hipStream_t st = net->stream;
+    TZ_HIP(hipMemcpyAsync(dev, host, in_bytes, hipMemcpyHostToDevice, st));
+    NetOut o;
+    rc = tz_net_forward_device(net, reinterpret_cast<const tz_state*>(dev + o_states), nullptr, nullptr, batch, batch, st, &o);
+    if (rc) return rc;
+    eval_pack_kernel<<<(int)((cells + 255) / 256), 256, 0, st>>>(o.policy, net->nn, o.policy_stride, reinterpret_cast<const uint16_t*>(dev + o_legal),
+                                                               reinterpret_cast<const int32_t*>(dev + o_cnt), amax, batch, o.value, o.variance,
+                                                               reinterpret_cast<float*>(dev + o_log), reinterpret_cast<float*>(dev + o_val),
+                                                               reinterpret_cast<float*>(dev + o_var));
+    TZ_HIP(hipGetLastError());
+    TZ_HIP(hipMemcpyAsync(host + o_log, dev + o_log, total - o_log, hipMemcpyDeviceToHost, st));
+    TZ_HIP(hipStreamSynchronize(st));
+    memcpy(logits_out, host + o_log, cells * 4);
+    memcpy(value_out, host + o_val, (size_t)batch * 4);
+    memcpy(variance_out, host + o_var, (size_t)batch * 4);
     for (size_t i = 0; i < cells; i++)
         if (logits_out[i] != logits_out[i]) return tz_fail(TZ_ENUMERIC, "tz_net_eval: NaN logit (net5.rs:263 panics)");
     return TZ_OK;
