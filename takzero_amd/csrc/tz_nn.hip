@@ -1922,7 +1922,10 @@ int launch_conv(const ConvArgs& a, int max_positions, int n_blocks_y, hipStream_
     constexpr int NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = LdsImg<LAYOUT>::bytes(LROWS);
     auto kern = conv_mfma_kernel<NB, P, RN, TAPS, FROM_STATE, ABL, SINGLE, NW, LAYOUT, ET, OCC>;
-    static bool attr_set = false;
+    static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
+    int attr_dev = 0;
+    TZ_HIP(hipGetDevice(&attr_dev));
+    bool& attr_set = attr_done[attr_dev & 63];
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -2024,7 +2027,10 @@ int launch_tower4x2(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + (size_t)9 * RT * 64 * 4;
     auto kern = tower4x2_mfma_kernel<NB, P>;
-    static bool attr_set = false;
+    static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
+    int attr_dev = 0;
+    TZ_HIP(hipGetDevice(&attr_dev));
+    bool& attr_set = attr_done[attr_dev & 63];
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -2040,7 +2046,10 @@ int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + ((OPT & 4096) ? (size_t)9 * RT * 64 * 4 : 0);
     auto kern = tower_mfma_kernel<NB, P, OPT, ET>;
-    static bool attr_set = false;
+    static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
+    int attr_dev = 0;
+    TZ_HIP(hipGetDevice(&attr_dev));
+    bool& attr_set = attr_done[attr_dev & 63];
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -2086,7 +2095,10 @@ int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
     const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
     auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM>;
-    static bool attr_set = false;
+    static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
+    int attr_dev = 0;
+    TZ_HIP(hipGetDevice(&attr_dev));
+    bool& attr_set = attr_done[attr_dev & 63];
     if (!attr_set) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
