@@ -50,7 +50,7 @@ static int reload_model(void* user) {
 
 int main(int argc, char** argv) {
     std::string directory, model, search = "gumbel";
-    int arch = TZ_ARCH_NET5, n = 5, blocks = 0, games = 128, sims = 768, moves = -1, exploration = 0, k = 64, precision = TZ_PREC_BF16;
+    int arch = TZ_ARCH_NET5, n = 5, blocks = 0, games = 128, sims = 768, moves = -1, exploration = 0, k = 64, precision = TZ_PREC_F16;
     double wait_limit = -1.0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
         else if (a == "--sampled-actions") k = atoi(next());
         else if (a == "--wait-limit") wait_limit = atof(next());
         else if (a == "--f16") precision = TZ_PREC_F16;
+        else if (a == "--bf16") precision = TZ_PREC_BF16;
         else if (a == "--exploration") exploration = 1;
         else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());

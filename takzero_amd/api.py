@@ -7,6 +7,7 @@ Method names, argument meaning and error behaviour follow the reference; randomn
 argument wherever the reference takes `rng` (the draws stay with the caller).
 Everything here is plumbing: the work happens in libtakzero_hip.so on the GPU."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -15,6 +16,10 @@ from ._lib import ROOT_INFO_DTYPE, STATE_DTYPE, TakzeroError, check
 
 ARCH_NET4_SIMHASH, ARCH_NET5, ARCH_NET6_SIMHASH, ARCH_TEST = 4, 5, 6, 100
 PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
+# The default 16-bit storage type of the MFMA path.  fp16 (fp32 accumulate) keeps policy / value logits within the north
+# star's 1e-3 of the fp32 graph through the 41 stacked convs (measured <= 1.5e-4); bf16 runs the same kernels 5 % faster
+# but lands at 1e-3 .. 7e-3.  TZ_PRECISION=bf16 (or precision=PREC_BF16) selects it.
+PREC_DEFAULT = {"bf16": PREC_BF16, "f16": PREC_F16, "f32": PREC_F32}[os.environ.get("TZ_PRECISION", "f16")]
 AGENT_NET, AGENT_DUMMY, AGENT_SIMPLE = 0, 1, 2
 EVAL_VALUE, EVAL_WIN, EVAL_LOSS, EVAL_DRAW = 0, 1, 2, 3
 TERMINAL_NONE, TERMINAL_WIN, TERMINAL_LOSS, TERMINAL_DRAW = -1, 0, 1, 2
@@ -82,9 +87,11 @@ def _states(states):
 class Net:
     """A network on one GPU.  `Net(arch=ARCH_NET5)` is Network::new; `load` is Network::load."""
 
-    def __init__(self, arch=ARCH_NET5, n=0, device=0, precision=PREC_BF16, blocks=0):
+    def __init__(self, arch=ARCH_NET5, n=0, device=0, precision=None, blocks=0):
         self.lib = _lib.load()
         h = C.c_void_p()
+        if precision is None:
+            precision = PREC_DEFAULT
         check(self.lib.tz_net_create(n, arch, device, precision, blocks, C.byref(h)))
         self.h = h
         self.arch, self.precision, self.blocks, self.device = arch, precision, blocks, device
@@ -129,7 +136,7 @@ class Net:
         return self
 
     @classmethod
-    def new(cls, arch=ARCH_NET5, seed=None, n=0, device=0, precision=PREC_BF16, blocks=0):
+    def new(cls, arch=ARCH_NET5, seed=None, n=0, device=0, precision=None, blocks=0):
         """Network::new(device, seed) (network/mod.rs:11): randomly initialised weights, tch's default initialisers."""
         from . import weights as W
 

@@ -41,12 +41,16 @@ struct Elem<__bf16> {
     typedef bf16x8 x8;
     typedef bf16x4 x4;
     static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ __bf16 cvt(float x) { return (__bf16)x; }
 };
 template <>
 struct Elem<_Float16> {
     typedef f16x8 x8;
     typedef f16x4 x4;
     static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    // stored activations saturate at the largest finite half instead of becoming inf (fp16's range is the one thing
+    // bf16 has over it; a trained net's activations are orders of magnitude below it)
+    static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)__builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f); }
 };
 
 
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void conv_mfma_kernel(ConvArgs a) {  
             } else {
                 ex4 ov;
 #pragma unroll
-                for (int k = 0; k < 4; k++) ov[k] = (ET)v[k];
+                for (int k = 0; k < 4; k++) ov[k] = Elem<ET>::cvt(v[k]);
                 *reinterpret_cast<ex4*>(reinterpret_cast<uint16_t*>(a.out) + o) = ov;
             }
         }
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                     const int r = rt * 16 + lr;
                     ex4 pk;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                     if (r < valid_rows) *reinterpret_cast<ex4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
                 }
             }
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                 if (to_second) {
                     const ex4 xv = *slot;
 #pragma unroll
@@ -799,7 +803,7 @@ __device__ __forceinline__ void tower4x2_body(const TowerArgs& a, unsigned char*
                     const int r = (tile0 + rt) * 16 + lr;
                     ex4 pk;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                     if (r < valid_rows) *reinterpret_cast<ex4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
                 }
             }
@@ -816,7 +820,7 @@ __device__ __forceinline__ void tower4x2_body(const TowerArgs& a, unsigned char*
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                 if (to_second) {
                     const ex4 xv = *slot;
 #pragma unroll
@@ -1266,7 +1270,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int rt = 0; rt < RT; rt++) {
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                 *reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = pk;
             }
     }
@@ -1299,7 +1303,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = (ET)(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
                 if (to_second) {
                     const ex4 xv = *slot;
 #pragma unroll

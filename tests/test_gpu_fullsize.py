@@ -23,7 +23,7 @@ def test_full_size_batch_agrees_with_a_small_one_and_with_the_oracle(oracle, arc
     A = require_gpu()
     from takzero_amd import weights as W
 
-    net = A.Net(arch=arch, n=n, precision=A.PREC_BF16, blocks=blocks)
+    net = A.Net(arch=arch, n=n, blocks=blocks)   # the default precision (fp16 storage)
     net.load_tensors(W.init_weights(arch, n=n, blocks=blocks, seed=123))
     rng = np.random.default_rng(7)
     choice = rng.integers(0, 16, B)

@@ -12,11 +12,12 @@ from gpu_util import random_positions, require_gpu
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
-# north_star: policy/value logits within 1e-3 of the fp32 LibTorch path.  That is the bar for the
-# fp32 validation path; the bf16 throughput path is held to a relative bound and its measured
-# error is printed.
+# north_star: policy/value logits within 1e-3 of the fp32 LibTorch path.  That is the bar for the default MFMA path
+# (fp16 storage, fp32 accumulate: measured <= 1.5e-4) and for the fp32 validation path.  The optional bf16 storage
+# (TZ_PRECISION=bf16, the same kernels, 5 % faster) cannot meet it through 41 stacked convs - one bf16 rounding is
+# already 2e-3 relative - and is held to the absolute bounds below (measured: logits <= 6.8e-3, value <= 2.4e-3).
 F32_TOL = 1e-3
-BF16_REL_TOL = 0.06
+BF16_LOGIT_TOL, BF16_VALUE_TOL = 1.2e-2, 5e-3
 
 
 def _planes(oracle, states):
@@ -80,14 +81,13 @@ def test_bf16_mfma_path_close_to_torch(oracle, arch, n, blocks, batch):
     A = require_gpu()
     err = _compare(A, oracle, arch, n, blocks, A.PREC_BF16, batch, 43, True)
     print("bf16 errors", err)
-    assert err["policy"] < BF16_REL_TOL * max(1.0, err["scale"])
-    assert err["value"] < BF16_REL_TOL and err["ube"] < 2 * BF16_REL_TOL
+    assert err["policy"] < BF16_LOGIT_TOL and err["value"] < BF16_VALUE_TOL and err["ube"] < BF16_VALUE_TOL
 
 
 @pytest.mark.parametrize("arch,n,blocks,batch", [(5, 5, 20, 21), (100, 5, 3, 19), (6, 6, 16, 7), (4, 4, 16, 15), (100, 3, 2, 33)])
 def test_f16_mfma_path_within_1e_3_of_torch(oracle, arch, n, blocks, batch):
-    """TZ_PREC_F16: the same MFMA kernels with IEEE fp16 storage meet the north star's 1e-3 logit/value tolerance
-    against the fp32 LibTorch graph, on the full nets, at the bf16 path's speed."""
+    """TZ_PREC_F16, the default: the MFMA kernels with IEEE fp16 storage meet the north star's 1e-3 logit/value tolerance
+    against the fp32 LibTorch graph, on the full nets."""
     A = require_gpu()
     err = _compare(A, oracle, arch, n, blocks, A.PREC_F16, batch, 44, False)
     print("f16 errors", err)

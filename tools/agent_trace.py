@@ -9,7 +9,7 @@ import takzero_amd.api as A
 from takzero_amd import weights as W
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+net = A.Net(arch=A.ARCH_NET5)
 net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
 mcts = A.BatchedMCTS(B, 5, 4, agent_kind=A.AGENT_DUMMY, node_capacity=256)
 mcts.new_openings(np.arange(B) % 16)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import takzero_amd.api as A
 from takzero_amd import weights as W
 
-net = A.Net(arch=A.ARCH_TEST, n=5, precision=A.PREC_BF16, blocks=1)
+net = A.Net(arch=A.ARCH_TEST, n=5, blocks=1)
 net.load_tensors(W.init_weights(W.ARCH_TEST, n=5, blocks=1, seed=1))
 pos = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 flop = 2 * 25 * 256 * 2304 * pos

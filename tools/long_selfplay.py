@@ -11,7 +11,7 @@ from takzero_amd import selfplay as SP
 from takzero_amd import weights as W
 
 games, sims, moves = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+net = A.Net(arch=A.ARCH_NET5)
 net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
 mcts = A.BatchedMCTS(games, 5, 4, agent=net)
 sp = SP.SelfPlay(mcts, sims, seed=0)

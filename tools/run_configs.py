@@ -17,7 +17,7 @@ from takzero_amd import weights as W
 
 
 def config4(moves=2, games=2048, sims=800):
-    net = A.Net(arch=A.ARCH_NET6_SIMHASH, precision=A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET6_SIMHASH)
     net.load_tensors(W.init_weights(W.ARCH_NET6_SIMHASH, seed=123))
     mcts = A.BatchedMCTS(games, 6, 4, agent=net)
     sp = SP.SelfPlay(mcts, sims, seed=0)
@@ -39,7 +39,7 @@ def config4(moves=2, games=2048, sims=800):
 
 
 def config5(games=4096, sims=1600, selfplay_moves=40, iterations=1):
-    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET5)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(games, 5, 4, agent=net)
     # synthetic replays.txt from the engine's own quick self-play (8 sims/move), SURVEY.md §8d config 5
@@ -76,7 +76,7 @@ def config5(games=4096, sims=1600, selfplay_moves=40, iterations=1):
 
 def config5_native(games=4096, sims=1600, selfplay_moves=40, iterations=1):
     """config 5 through the native drivers (csrc/tz_host.cpp): self-play writes replays.txt, reanalyze tails it."""
-    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET5)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(games, 5, 4, agent=net)
     sp = SP.NativeSelfPlay(mcts, 8, seed=1, search="puct")
@@ -110,7 +110,7 @@ def config5_native(games=4096, sims=1600, selfplay_moves=40, iterations=1):
 def gumbel(moves=3, games=4096, budget=768, k=64):
     """What the reference's selfplay binary runs today (selfplay/src/main.rs:138-153): Gumbel sequential halving,
     64 sampled actions, budget 768, on 5x5 / net5."""
-    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET5)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(games, 5, 4, agent=net)
     sp = SP.SelfPlay(mcts, budget, seed=0, search="gumbel", sampled_actions=k)
@@ -136,7 +136,7 @@ def directory_loop(moves=100, games=4096, sims=400):
     appender thread) against the bare search loop of bench.py, over enough moves that games finish and targets flow."""
     from takzero_amd import runner as R
 
-    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET5)
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(games, 5, 4, agent=net)
     d = tempfile.mkdtemp()

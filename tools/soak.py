@@ -13,7 +13,7 @@ from takzero_amd import runner as R
 from takzero_amd import weights as W
 
 moves = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+net = A.Net(arch=A.ARCH_NET5)
 net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
 mcts = A.BatchedMCTS(4096, 5, 4, agent=net)
 d = tempfile.mkdtemp()

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import takzero_amd.api as A
 from takzero_amd import weights as W
 
-net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)
+net = A.Net(arch=A.ARCH_NET5)
 net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
 variants = [int(v) for v in sys.argv[1:]] or [0, 1]
 flop = 40 * 2 * 25 * 256 * 2304 * 4096

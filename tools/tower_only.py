@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import takzero_amd.api as A
 from takzero_amd import weights as W
 
-net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_BF16)  # default TZ_TOWER=2: fused net kernel
+net = A.Net(arch=A.ARCH_NET5)  # default TZ_TOWER=2: fused net kernel
 net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
 mcts = A.BatchedMCTS(4096, 5, 4, agent=net, node_capacity=2048)
 mcts.new_openings(np.arange(4096) % 16)
