@@ -61,3 +61,47 @@ def test_engine_matches_oracle_search_with_same_net(oracle, arch, n, blocks, pre
         choice = rng.integers(0, 16, B)
         assert np.array_equal(gpu.restart_terminal_envs(choice), ora.restart_terminal(choice))
     assert gpu.counters() == ora.counters()
+
+
+def test_search_with_the_fp16_net_agrees_with_the_fp32_path_on_moves_and_visits():
+    """North star: visit counts and chosen moves match the reference's fp32 path.  Bit-exactness of the tree is proven
+    against the oracle fed the same network outputs (above); this is the other half: the default 16-bit network
+    (logits within 1.5e-4 of fp32) against the fp32 validation network (within 1.5e-6 of LibTorch) under the same search,
+    same roots, same Dirichlet noise - how far do 1e-4 differences in the logits move 400-simulation searches?"""
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    n, B, sims = 5, 128, 400
+    w = W.init_weights(W.ARCH_NET5, seed=123)
+    rng = np.random.default_rng(7)
+    choice = rng.integers(0, 16, B)
+    results = {}
+    noise = None
+    for name, prec in (("f32", A.PREC_F32), ("f16", A.PREC_F16), ("bf16", A.PREC_BF16)):
+        net = A.Net(arch=A.ARCH_NET5, precision=prec).load_tensors(w)
+        mcts = A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 15)
+        mcts.new_openings(choice)
+        betas = np.zeros(B, np.float32)
+        mcts.simulate(betas, 1)
+        if noise is None:
+            info = mcts.root_info()
+            amax = int(info["n_children"].max())
+            noise = np.zeros((B, amax), np.float32)
+            for g in range(B):
+                noise[g, :info["n_children"][g]] = rng.dirichlet([0.05] * int(info["n_children"][g])).astype(np.float32)
+        mcts.apply_noise(noise, 0.25)
+        mcts.simulate(betas, sims)
+        ch = mcts.root_children()
+        results[name] = (mcts.select_best_actions().copy(), ch["visits"].astype(np.float64), ch["move_idx"].copy())
+        mcts.close()
+        net.close()
+    ref_act, ref_vis, ref_moves = results["f32"]
+    for name, min_same, max_tv in (("f16", 0.97, 0.02), ("bf16", 0.85, 0.10)):
+        act, vis, moves = results[name]
+        assert np.array_equal(moves, ref_moves)
+        same = float((act == ref_act).mean())
+        tv = 0.5 * np.abs(vis / vis.sum(1, keepdims=True) - ref_vis / ref_vis.sum(1, keepdims=True)).sum(1)
+        identical = float((vis == ref_vis).all(1).mean())
+        print("%s vs f32: same chosen move %.3f of games, identical visit counts %.3f of games, total-variation distance of "
+              "the visit distributions mean %.4f max %.4f" % (name, same, identical, tv.mean(), tv.max()))
+        assert same >= min_same and tv.mean() <= max_tv
