@@ -42,6 +42,7 @@ struct Elem<__bf16> {
     typedef bf16x4 x4;
     static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ __bf16 cvt(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ __bf16 relu_cvt(float x) { return (__bf16)(x > 0.f ? x : 0.f); }
 };
 template <>
 struct Elem<_Float16> {
@@ -50,7 +51,8 @@ struct Elem<_Float16> {
     static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     // stored activations saturate at the largest finite half instead of becoming inf (fp16's range is the one thing
     // bf16 has over it; a trained net's activations are orders of magnitude below it)
-    static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)__builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f); }
+    static __device__ __forceinline__ _Float16 cvt(float x) { return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+    static __device__ __forceinline__ _Float16 relu_cvt(float x) { return (_Float16)__builtin_amdgcn_fmed3f(x, 0.0f, 65504.0f); }  // ReLU and saturation in one v_med3
 };
 
 
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                     const int r = rt * 16 + lr;
                     ex4 pk;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
                     if (r < valid_rows) *reinterpret_cast<ex4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
                 }
             }
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
                 if (to_second) {
                     const ex4 xv = *slot;
 #pragma unroll
@@ -803,7 +805,7 @@ __device__ __forceinline__ void tower4x2_body(const TowerArgs& a, unsigned char*
                     const int r = (tile0 + rt) * 16 + lr;
                     ex4 pk;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
                     if (r < valid_rows) *reinterpret_cast<ex4*>(a.out + (m0 + r) * FILTERS + cbase) = pk;
                 }
             }
@@ -820,7 +822,7 @@ __device__ __forceinline__ void tower4x2_body(const TowerArgs& a, unsigned char*
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
                 if (to_second) {
                     const ex4 xv = *slot;
 #pragma unroll
@@ -1270,7 +1272,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int rt = 0; rt < RT; rt++) {
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
                 *reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = pk;
             }
     }
@@ -1303,7 +1305,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::cvt(acc[rt][j][k] > 0.f ? acc[rt][j][k] : 0.f);
+                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
                 if (to_second) {
                     const ex4 xv = *slot;
 #pragma unroll
