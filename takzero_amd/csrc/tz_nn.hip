@@ -1003,10 +1003,18 @@ struct RowMap {
         }
         return k;
     }
+    // the inverse of square_at (tables: checked against it at compile time, row_map_is_permutation)
     __host__ __device__ static constexpr int place_of(int square) {
-        for (int k = 0; k < NN; k++)
-            if (square_at(k) == square) return k;
-        return -1;
+        if (PERM && NB == 5) {
+            constexpr int I[25] = {24, 0, 1, 2, 3, 4, 15, 16, 17, 12, 5, 18, 19, 20, 13, 6, 21, 22, 23, 14, 7, 8, 9, 10, 11};
+            return I[square];
+        }
+        if (PERM && NB == 6) {
+            constexpr int I[36] = {16, 1, 0, 3, 2, 17, 5, 20, 21, 22, 23, 12, 4, 25, 24, 27, 26, 13,
+                                   7, 28, 29, 30, 31, 14, 6, 33, 32, 35, 34, 15, 19, 8, 9, 10, 11, 18};
+            return I[square];
+        }
+        return square;
     }
     __host__ __device__ static constexpr int row_of(int board, int square) {
         if (!PERM) return board * NN + square;
@@ -1048,6 +1056,8 @@ constexpr bool row_map_is_permutation() {
         for (int k = 0; k < NB * NB; k++) seen += RM::square_at(k) == sq;
         if (seen != 1) return false;
     }
+    for (int k = 0; k < NB * NB; k++)
+        if (RM::place_of(RM::square_at(k)) != k) return false;
     for (int b = 0; b < P; b++)
         for (int sq = 0; sq < NB * NB; sq++) {
             int board = -1, back = -1;
@@ -1224,8 +1234,9 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         const int plane = i >> 5, zr = (i >> 2) & 7, pc = i & 3;
         *reinterpret_cast<uint4*>(lds + plane * PLANE + (ZROW + zr) * LDS_ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
     }
-    if (wave == 7) {  // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier)
-        for (int tap = 0; tap < TAPS; tap++) {
+    {   // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier): wave w computes
+        // taps w and w + 8
+        for (int tap = wave; tap < TAPS; tap += 8) {
             int tb[RT];
             if constexpr (PERM) tap_bases_map<NB, P, true, LAYOUT>(tap, lr, q, ZROW, tb);
             else tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
@@ -1247,8 +1258,30 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
         }
+        // one 32-channel chunk of input planes (3x3 .. 5x5): all 18 weight fragments of the wave are requested before the
+        // barrier, so that the nine taps do not each wait for their own round trip to L2
+        const bool one_chunk = a.kc_in == 1;
+        ex8 bw[TAPS][RN];
+        if (one_chunk) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; tap++)
+#pragma unroll
+                for (int j = 0; j < RN; j++)
+                    bw[tap][j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (tap * 16 + ct0 + j) * 1024, 0));
+        }
         __syncthreads();
-        for (int tap = 0; tap < TAPS; tap++) {
+        if (one_chunk) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; tap++) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    const ex8 av = *reinterpret_cast<const ex8*>(lds + tap_table[(tap * RT + rt) * 64 + lane]);
+#pragma unroll
+                    for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(bw[tap][j], av, acc[rt][j]);
+                }
+            }
+        }
+        for (int tap = 0; tap < (one_chunk ? 0 : TAPS); tap++) {
             int abase[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
