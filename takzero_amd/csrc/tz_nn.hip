@@ -1208,6 +1208,20 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     const int ct0 = wave * RN;
     const int lane16 = lane * 16;
 
+    // ---- the workgroup's packed states, copied into LDS in one round trip (plane 7 of the image is free until the first
+    // conv's epilogue): game_repr walks every square of a state with data-dependent branches, which from global memory
+    // is a chain of dependent loads per thread
+    static_assert(sizeof(tz_state) % 4 == 0 && P * sizeof(tz_state) <= (size_t)RT * 16 * LDS_ROWB, "state staging fits a plane");
+    {
+        constexpr int DW = sizeof(tz_state) / 4;
+        uint32_t* stage = reinterpret_cast<uint32_t*>(lds + 7 * PLANE);
+        for (int i = tid; i < valid_boards * DW; i += NT) {
+            const int b = i / DW, d = i - b * DW, pos = pos0 + b;
+            stage[i] = reinterpret_cast<const uint32_t*>(a.states + (a.game_index ? a.game_index[pos] : pos))[d];
+        }
+        __syncthreads();
+    }
+    const tz_state* staged = reinterpret_cast<const tz_state*>(lds + 7 * PLANE);
     // ---- game_repr into planes 0..kc_in-1; zero rows of every plane
     for (int row = tid; row < LROWS; row += NT) {
         int board = 0, px = -1;
@@ -1216,8 +1230,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         const tz_state* s = nullptr;
         int fd = 0;
         if (ok) {
-            const int pos = pos0 + board;
-            s = a.states + (a.game_index ? a.game_index[pos] : pos);
+            s = staged + board;
             fd = state_flat_diff<NB>(s);
         }
         for (int c8 = 0; c8 < a.kc_in * 4; c8++) {
