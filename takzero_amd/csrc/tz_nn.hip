@@ -901,6 +901,8 @@ struct NetArgs {
     const float* heads;     // heads_kernel layout
     float* value;
     float* ube;
+    void* rnd_in;           // if set: the RND networks' input x / sum(x^2) (net5.rs:127) is written here, [pos][rnd_stride]
+    int rnd_stride;         // elements; index inside a position = square * cin_real + plane (cin_real % 8 == 0)
 };
 
 // 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
@@ -1233,15 +1235,19 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             s = staged + board;
             fd = state_flat_diff<NB>(s);
         }
+        float ssq = 0.0f;   // sum of squares of this square's planes, in plane order (for the RND input below)
         for (int c8 = 0; c8 < a.kc_in * 4; c8++) {
             ex8 v;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int c = c8 * 8 + k;
-                v[k] = (ET)((ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f);
+                const float pv = (ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f;
+                ssq += pv * pv;
+                v[k] = (ET)pv;
             }
             *reinterpret_cast<ex8*>(lds + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = v;
         }
+        if (row < RT * 16) hscratch[row] = ssq;
     }
     for (int i = tid; i < 8 * 8 * 4; i += NT) {  // 8 planes x 8 zero rows x 4 pieces of 16 B
         const int plane = i >> 5, zr = (i >> 2) & 7, pc = i & 3;
@@ -1283,6 +1289,27 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                     bw[tap][j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (tap * 16 + ct0 + j) * 1024, 0));
         }
         __syncthreads();
+        // ---- RND input (RndNetwork::normalize, net5.rs:127): x / sum(x^2) over the whole position, written once per
+        // position by the threads that built its squares; the sum adds the squares' partial sums in square order, so it
+        // does not depend on the row order or on the boards per workgroup
+        if (a.rnd_in) {
+            for (int row = tid; row < RT * 16; row += NT) {
+                int board = 0, px = -1;
+                RM::decode(row, board, px);
+                if (px < 0 || board >= valid_boards) continue;
+                float ss = 0.0f;
+                for (int sq = 0; sq < NN; sq++) ss += hscratch[RM::row_of(board, sq)];
+                const tz_state* s = staged + board;
+                const int fd = state_flat_diff<NB>(s);
+                ET* out = reinterpret_cast<ET*>(a.rnd_in) + (size_t)(pos0 + board) * a.rnd_stride + px * a.cin_real;
+                for (int c8 = 0; c8 < a.cin_real / 8; c8++) {
+                    ex8 v;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = (ET)(plane_value<NB>(s, px, c8 * 8 + k, fd) / ss);
+                    *reinterpret_cast<ex8*>(out + c8 * 8) = v;
+                }
+            }
+        }
         if (one_chunk) {
 #pragma unroll
             for (int tap = 0; tap < TAPS; tap++) {
@@ -2201,6 +2228,12 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
     return tz_fail(TZ_EINVAL, "net: unsupported board size");
 }
 
+// RND input from the fused kernel: net5 only (in_size 800 = 25 squares x 32 planes, no K padding, 8 planes per 16-B store)
+bool net_fused_writes_rnd_input(const tz_net* net) {
+    static const bool separate = getenv("TZ_RND_PREP_KERNEL") != nullptr;   // A/B: the separate rnd_prep_state_kernel
+    return !separate && net->has_rnd && net->n == 5 && net->cin % 8 == 0 && (net->cin * net->nn) % 32 == 0;
+}
+
 int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const int32_t* count_dev, int count_host,
               int max_positions, hipStream_t st) {
     NetArgs a;
@@ -2222,6 +2255,12 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.heads = net->heads;
     a.value = net->value;
     a.ube = net->ube;
+    a.rnd_in = nullptr;
+    a.rnd_stride = 0;
+    if (net_fused_writes_rnd_input(net)) {   // the fused kernel also writes the RND networks' normalised input
+        a.rnd_in = net->rnd_in;
+        a.rnd_stride = net->cin * net->nn;
+    }
     if (net->precision == TZ_PREC_F16) return net_fused_et<_Float16>(net, a, max_positions, st);
     return net_fused_et<__bf16>(net, a, max_positions, st);
 }
@@ -2414,8 +2453,10 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         if (bf) {
             // 3 launches: input planes straight from the packed states, layer 1 of both nets as one GEMM,
             // layers 2 and 3 as grouped launches (blockIdx.z = net)
+            const bool fused_wrote_it = net->blocks > 0 && net->tower_w && net_fused_mode() == 2 && net_fused_writes_rnd_input(net);
             switch (net->n) {
                 case 5:
+                    if (fused_wrote_it) break;   // net_mfma_kernel wrote x / sum(x^2) while it built the planes
                     if (net->precision == TZ_PREC_F16)
                         rnd_prep_state_kernel<5, _Float16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (_Float16*)net->rnd_in);
                     else

@@ -36,6 +36,9 @@ def child(n, out):
             raw = net.forward_raw(states)
             for k, v in zip(("policy", "value", "ube"), raw):
                 res["%s_%d_%s" % (pname, count, k)] = np.asarray(v)
+            # the Agent surface too: its variance carries the RND networks' output (net5)
+            _, _, var = net.policy_value_uncertainty(states, [np.zeros(1, np.uint16)] * count)
+            res["%s_%d_variance" % (pname, count)] = np.asarray(var)
     np.savez(out, **res)
 
 
