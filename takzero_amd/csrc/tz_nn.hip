@@ -1813,7 +1813,11 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
                         for (int j = 0; j < 8; j++) {
                             const int ci = kc * 32 + 8 * (lane >> 4) + j;
                             if (ci >= cin) continue;
-                            p[((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j] = precision == TZ_PREC_F16 ? f2h(W(co, ci, t)) : f2bf(W(co, ci, t));
+                            const float wv = W(co, ci, t);
+                            // fp16 storage: a (BatchNorm-folded) weight beyond the largest finite half would become inf
+                            if (precision == TZ_PREC_F16 && !(wv >= -65504.0f && wv <= 65504.0f))
+                                return tz_fail(TZ_ENUMERIC, "weights: a folded weight is outside fp16's range (or not finite); load this model with TZ_PREC_BF16");
+                            p[((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j] = precision == TZ_PREC_F16 ? f2h(wv) : f2bf(wv);
                         }
                     }
         return upload(p, &L->w_mfma);

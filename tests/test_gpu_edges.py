@@ -102,3 +102,25 @@ def test_empty_overwrite_and_boundary_errors(oracle):
     unloaded = A.Net(arch=A.ARCH_TEST, n=4, blocks=1)
     with pytest.raises(A.TakzeroError):
         unloaded.forward_raw(gpu.get_positions())  # no weights yet
+
+
+def test_fp16_storage_refuses_a_weight_outside_its_range_and_keeps_the_old_model():
+    """fp16 storage (the default): a folded weight beyond 65504 would become inf; the load fails with TZ_ENUMERIC and, as with
+    any failed load (selfplay/src/main.rs:112-115), the previous weights stay active; bf16 storage takes the same tensors."""
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_TEST, n=5, blocks=1, seed=2)
+    net = A.Net(arch=A.ARCH_TEST, n=5, precision=A.PREC_F16, blocks=1).load_tensors(w)
+    oracle = O.load()
+    states = O.states_array(random_positions(oracle, O, 5, 4, 6, 4, max_ply=20))
+    before = net.forward_raw(states)
+    bad = {k: v.copy() for k, v in w.items()}
+    name = next(k for k in bad if k.endswith("conv2d.weight") and "res_block" in k)
+    bad[name].flat[3] = 1.0e6
+    with pytest.raises(A.TakzeroError):
+        net.load_tensors(bad)
+    after = net.forward_raw(states)
+    for x, y in zip(before, after):
+        assert np.array_equal(x, y)
+    A.Net(arch=A.ARCH_TEST, n=5, precision=A.PREC_BF16, blocks=1).load_tensors(bad)
