@@ -1454,10 +1454,12 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) pacc[rt][j] = b4;
         }
-        k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, [&](int tap, int kc, int j) -> ex8 {
+        auto wlp = [&](int tap, int kc, int j) -> ex8 {
             const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
             return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
-        });
+        };
+        if constexpr (PERM) k_loop_256_skip<NB, P, RNP, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+        else k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
 #pragma unroll
         for (int j = 0; j < RNP; j++) {
             const int cbase = (ctp + j) * 16 + q * 4;
