@@ -1403,24 +1403,41 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         const float bv = lu[NN], bu = lu[NN + 1], lbv = lu[NN + 2], lbu = lu[NN + 3];
         const int hplane = lane >> 3, hpiece = (lane & 7) >> 1, hhalf = lane & 1;  // channels 4*lane .. 4*lane+3
         constexpr int HROWS = PERM ? RT * 16 : ROWS;
-        for (int row = wave; row < HROWS; row += 8) {
-            const ex4 xv = *reinterpret_cast<const ex4*>(lds + hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8);
-            float dv = 0.f, du = 0.f;
+        // four rows per step: the 64-lane reductions of a row are a chain of six dependent cross-lane moves, four rows
+        // give the pipeline four independent chains (same reduction tree per row, so the same bits)
+        constexpr int HU = 4;
+        for (int row0 = wave; row0 < HROWS; row0 += 8 * HU) {
+            float dv[HU], du[HU];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                dv += (float)xv[k] * wv[k];
-                du += (float)xv[k] * wu[k];
+            for (int u = 0; u < HU; u++) {
+                const int row = min(row0 + 8 * u, HROWS - 1);
+                const ex4 xv = *reinterpret_cast<const ex4*>(lds + hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8);
+                dv[u] = 0.f;
+                du[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    dv[u] += (float)xv[k] * wv[k];
+                    du[u] += (float)xv[k] * wu[k];
+                }
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
-                dv += __shfl_xor(dv, d);
-                du += __shfl_xor(du, d);
+#pragma unroll
+                for (int u = 0; u < HU; u++) {
+                    dv[u] += __shfl_xor(dv[u], d);
+                    du[u] += __shfl_xor(du[u], d);
+                }
             }
             if (lane == 0) {
-                dv += bv;
-                du += bu;
-                hscratch[row] = dv > 0.f ? dv : 0.f;
-                hscratch[RT * 16 + row] = du > 0.f ? du : 0.f;
+#pragma unroll
+                for (int u = 0; u < HU; u++) {
+                    const int row = row0 + 8 * u;
+                    if (row < HROWS) {
+                        const float a = dv[u] + bv, b = du[u] + bu;
+                        hscratch[row] = a > 0.f ? a : 0.f;
+                        hscratch[RT * 16 + row] = b > 0.f ? b : 0.f;
+                    }
+                }
             }
         }
         __syncthreads();
