@@ -48,7 +48,7 @@ KERNEL_NAME = {0: "conv_mfma_kernel<5,8,2,9,false,0,true,8,1> (one 3x3 256->256 
 # `issued` figures beside the algorithmic ones:
 SQUARE_MAJOR = os.environ.get("TZ_NET_ROWS", "square") != "board"
 TOWER_TILE_TAPS = (91 if SQUARE_MAJOR else 117, 117)
-ISSUED_FLOP_PER_LAUNCH_POS = (2 * 16 * 256 * 32 * (9 * 13 * 2 + TOWER_LAYERS * TOWER_TILE_TAPS[0] * 8 + 9 * 13 * 8 * 0.5)) / 8.0
+ISSUED_FLOP_PER_LAUNCH_POS = (2 * 16 * 256 * 32 * (9 * 13 * 1 + TOWER_LAYERS * TOWER_TILE_TAPS[0] * 8 + TOWER_TILE_TAPS[0] * 8 * 0.5)) / 8.0   # first conv (one 32-plane chunk) + tower + policy conv (128 of 256 columns)
 FUSED_TOWER = FUSED_MODE >= 1
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense MFMA peak of the 16-bit types (f16 = bf16), MI355X_MICROARCH.md
 
