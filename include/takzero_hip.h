@@ -97,8 +97,11 @@ typedef struct tz_search tz_search; /* opaque: BatchedMCTS<B, Game<N,HALF_KOMI>>
 /* arithmetic of the trunk */
 #define TZ_PREC_BF16 0 /* NHWC bf16 activations/weights, fp32 accumulate on MFMA: 5 % faster, logits 1e-3..7e-3 off fp32 */
 #define TZ_PREC_F32 1  /* fp32 everywhere on plain FMA kernels (validation path)                          */
-#define TZ_PREC_F16 2  /* the recommended default: the same MFMA kernels with IEEE fp16 storage (saturating), fp32
-                          accumulate: logits within 1e-3 of fp32 (measured 1.5e-4), the north star's tolerance */
+#define TZ_PREC_F16 2  /* the throughput default: the same MFMA kernels with IEEE fp16 storage (saturating), fp32
+                          accumulate: logits within ~2e-4 relative of fp32 (1.5e-4 absolute at random-init scale) */
+#define TZ_PREC_F16X2 3 /* split precision: every operand a hi/lo pair of halves (22-bit significand), three fp16 MFMAs
+                          per product with fp32 accumulate: logits within 1e-3 absolute of the fp32 LibTorch graph at
+                          trained logit scale (|logit| ~ 10), the north star's tolerance; ~3x the MFMA work */
 
 /* built-in agents for tz_search_create (takzero/src/search/agent.rs:16-87) */
 #define TZ_AGENT_NET 0

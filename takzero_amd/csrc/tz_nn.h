@@ -8,7 +8,8 @@
 
 struct ConvW {
     int taps = 0, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
-    uint16_t* w_mfma = nullptr;  // bf16 bits, fragment order [tap][kc][ct][lane][8]
+    uint16_t* w_mfma = nullptr;  // bf16 / fp16 bits, fragment order [tap][kc][ct][lane][8]
+    uint16_t* w_lo = nullptr;    // TZ_PREC_F16X2: fp16((w - hi) * 2^11) in the same order
     float* w_f32 = nullptr;      // [tap][cout][cin]
     float* bias = nullptr;       // [cout_pad]  (BatchNorm folded in)
 };
@@ -21,6 +22,7 @@ struct tz_net {
     ConvW conv_in, policy;
     std::vector<ConvW> res;  // 2 per block
     uint16_t* tower_w = nullptr;  // all residual-tower layers back to back (fused tower kernel)
+    uint16_t* tower_w_lo = nullptr;  // TZ_PREC_F16X2: their lo halves
     float* tower_bias = nullptr;  // [2*blocks][256]
     float* heads = nullptr;  // [value conv w 256, ube conv w 256, value lin nn, ube lin nn, bv, bu, lbv, lbu]
     ConvW rnd[2][3];         // [learning, target][input, hidden, final]  (fp32 path)

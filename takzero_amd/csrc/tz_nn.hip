@@ -903,6 +903,10 @@ struct NetArgs {
     float* ube;
     void* rnd_in;           // if set: the RND networks' input x / sum(x^2) (net5.rs:127) is written here, [pos][rnd_stride]
     int rnd_stride;         // elements; index inside a position = square * cin_real + plane (cin_real % 8 == 0)
+    // split precision (SP = 1): the lo halves of the three weight buffers, same fragment order
+    const uint16_t* w_in_lo;
+    const uint16_t* w_lo;
+    const uint16_t* w_pol_lo;
 };
 
 // 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
@@ -1187,18 +1191,134 @@ __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const 
     one_tap(IntC<8>{});
 }
 
-template <int NB, int P, int RNP, typename ET, bool PERM = false>
+// ---------------------------------------------------------------------------------------------
+// Split precision (TZ_PREC_F16X2).  Every operand is a pair of halves: hi = fp16(x) and lo = fp16((x - hi) * 2^11), a
+// 22-bit significand; the image holds 16 planes (0..7 hi, 8..15 lo), the weights two buffers in the same fragment order.
+// A product is three MFMAs with fp32 accumulation: wh*xh into the main accumulator, wl*xh and wh*xl into a correction
+// accumulator that is scaled by 2^-11 once per layer (the lo*lo term is below fp32's own rounding); fp16 x fp16 products
+// are exact in fp32, so the layer is an fp32 convolution of 22-bit operands.  Same k order, tap table, row maps and
+// skipped (tap, tile) pairs as k_loop_256_skip; weight fragments one k-step ahead (a k-step is 6 MFMAs per row tile).
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+template <int NB, int P, bool PERM, int RNX, int PLANE, typename WL>
+__device__ __forceinline__ void k_loop_split(const unsigned char* lds, const int* tap_table, int lane,
+                                             f32x4 (&accm)[RowMap<NB, P, PERM>::RT][RNX], f32x4 (&accc)[RowMap<NB, P, PERM>::RT][RNX], WL wl) {
+    typedef Elem<_Float16> E;
+    typedef f16x8 ex8;
+    typedef RowMap<NB, P, PERM> RM;
+    constexpr int TAPS = 9, RT = RM::RT, LO = 8 * PLANE;
+    ex8 bq[2][RNX][2];
+#pragma unroll
+    for (int j = 0; j < RNX; j++) {
+        bq[0][j][0] = wl(0, 0, j, 0);
+        bq[0][j][1] = wl(0, 0, j, 1);
+    }
+    int abase[RT];
+    ex8 ah[RT], al[RT];
+    {
+        constexpr unsigned M0 = RM::tap_tile_mask(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            if ((M0 >> rt) & 1) abase[rt] = tap_table[rt * 64 + lane];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            if ((M0 >> rt) & 1) {
+                ah[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                al[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + LO);
+            }
+    }
+    auto one_tap = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr unsigned NOW = RM::tap_tile_mask(tap);
+        constexpr unsigned NEXT = tap + 1 < TAPS ? RM::tap_tile_mask(tap + 1 < TAPS ? tap + 1 : tap) : 0u;
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            if (kc + 1 < 8) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) {
+                    bq[(kc + 1) & 1][j][0] = wl(tap, kc + 1, j, 0);
+                    bq[(kc + 1) & 1][j][1] = wl(tap, kc + 1, j, 1);
+                }
+            } else if (tap + 1 < TAPS) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) {
+                    bq[(kc + 1) & 1][j][0] = wl(tap + 1, 0, j, 0);
+                    bq[(kc + 1) & 1][j][1] = wl(tap + 1, 0, j, 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc == 7) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    if ((NEXT >> rt) & 1) abase[rt] = tap_table[((tap + 1) * RT + rt) * 64 + lane];
+            }
+            if (kc == 4) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+                    if ((NOW >> rt) & 1) {
+                        abase[rt] += 4 * PLANE;
+                        asm volatile("" : "+v"(abase[rt]));
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                if ((NOW >> rt) & 1) {
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) accm[rt][j] = E::mfma(bq[kc & 1][j][0], ah[rt], accm[rt][j]);
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) accc[rt][j] = E::mfma(bq[kc & 1][j][1], ah[rt], accc[rt][j]);
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) accc[rt][j] = E::mfma(bq[kc & 1][j][0], al[rt], accc[rt][j]);
+                }
+                if (kc < 7) {
+                    if ((NOW >> rt) & 1) {
+                        const int off = abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE;
+                        ah[rt] = *reinterpret_cast<const ex8*>(lds + off);
+                        al[rt] = *reinterpret_cast<const ex8*>(lds + off + LO);
+                    }
+                } else if ((NEXT >> rt) & 1) {
+                    ah[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                    al[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + LO);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                if ((NOW >> rt) & 1) __builtin_amdgcn_sched_group_barrier(0x008, 3 * RNX, 0);
+                if (kc < 7 ? ((NOW >> rt) & 1) : ((NEXT >> rt) & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
+    };
+    one_tap(IntC<0>{});
+    one_tap(IntC<1>{});
+    one_tap(IntC<2>{});
+    one_tap(IntC<3>{});
+    one_tap(IntC<4>{});
+    one_tap(IntC<5>{});
+    one_tap(IntC<6>{});
+    one_tap(IntC<7>{});
+    one_tap(IntC<8>{});
+}
+
+// hi / lo halves of an fp32 value (both saturating)
+__device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo) {
+    hi = Elem<_Float16>::cvt(v);
+    lo = Elem<_Float16>::cvt((v - (float)hi) * SPLIT_SCALE);
+}
+
+// SP = 1: split precision (k_loop_split): 16 image planes (hi 0..7, lo 8..15), two accumulator sets, hi / lo weight buffers.
+template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0>
 __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
+    static_assert(!SP || sizeof(ET) == 2, "split precision runs on fp16 halves");
     constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
     typedef RowMap<NB, P, PERM> RM;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
+    constexpr int NPL = SP ? 16 : 8, LO = 8 * PLANE;   // image planes; byte offset of the lo half of a plane
     constexpr int LAYER_FRAGS = TAPS * 8 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* hscratch = reinterpret_cast<float*>(lds + 8 * PLANE);  // [2][RT*16] head pre-activations
-    int* tap_table = reinterpret_cast<int*>(lds + 8 * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes]
+    float* hscratch = reinterpret_cast<float*>(lds + NPL * PLANE);  // [2][RT*16] head pre-activations
+    int* tap_table = reinterpret_cast<int*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes]
     const int count = a.count_dev ? *a.count_dev : a.count_host;
     const int pos0 = blockIdx.x * P;
     if (pos0 >= count) return;
@@ -1237,19 +1357,21 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         }
         float ssq = 0.0f;   // sum of squares of this square's planes, in plane order (for the RND input below)
         for (int c8 = 0; c8 < a.kc_in * 4; c8++) {
-            ex8 v;
+            ex8 v, vl;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int c = c8 * 8 + k;
                 const float pv = (ok && c < a.cin_real) ? plane_value<NB>(s, px, c, fd) : 0.0f;
                 ssq += pv * pv;
                 v[k] = (ET)pv;
+                if constexpr (SP) vl[k] = (ET)((pv - (float)v[k]) * SPLIT_SCALE);
             }
             *reinterpret_cast<ex8*>(lds + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = v;
+            if constexpr (SP) *reinterpret_cast<ex8*>(lds + LO + LdsImg<LAYOUT>::store_addr(row, c8, PLANE)) = vl;
         }
         if (row < RT * 16) hscratch[row] = ssq;
     }
-    for (int i = tid; i < 8 * 8 * 4; i += NT) {  // 8 planes x 8 zero rows x 4 pieces of 16 B
+    for (int i = tid; i < NPL * 8 * 4; i += NT) {  // planes x 8 zero rows x 4 pieces of 16 B
         const int plane = i >> 5, zr = (i >> 2) & 7, pc = i & 3;
         *reinterpret_cast<uint4*>(lds + plane * PLANE + (ZROW + zr) * LDS_ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -1268,6 +1390,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     for (int j = 0; j < RN; j++) obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
 
     f32x4 acc[RT][RN];
+    f32x4 accc[SP ? RT : 1][RN];   // split precision: the correction accumulator (wl*xh + wh*xl), scaled by 2^-11 per layer
     // ---- first conv: cin_pad = 32*kc_in channels, 9*kc_in k-steps
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_in), 0, TAPS * a.kc_in * 16 * 1024, 0x00020000);
@@ -1279,14 +1402,16 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         }
         // one 32-channel chunk of input planes (3x3 .. 5x5): all 18 weight fragments of the wave are requested before the
         // barrier, so that the nine taps do not each wait for their own round trip to L2
-        const bool one_chunk = a.kc_in == 1;
-        ex8 bw[TAPS][RN];
-        if (one_chunk) {
+        const bool one_chunk = !SP && a.kc_in == 1;
+        ex8 bw[SP ? 1 : TAPS][RN];
+        if constexpr (!SP) {
+            if (one_chunk) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; tap++)
+                for (int tap = 0; tap < TAPS; tap++)
 #pragma unroll
-                for (int j = 0; j < RN; j++)
-                    bw[tap][j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (tap * 16 + ct0 + j) * 1024, 0));
+                    for (int j = 0; j < RN; j++)
+                        bw[tap][j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (tap * 16 + ct0 + j) * 1024, 0));
+            }
         }
         __syncthreads();
         // ---- RND input (RndNetwork::normalize, net5.rs:127): x / sum(x^2) over the whole position, written once per
@@ -1310,31 +1435,66 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 }
             }
         }
-        if (one_chunk) {
+        if constexpr (!SP) {
+            if (one_chunk) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; tap++) {
+                for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    const ex8 av = *reinterpret_cast<const ex8*>(lds + tap_table[(tap * RT + rt) * 64 + lane]);
+                    for (int rt = 0; rt < RT; rt++) {
+                        const ex8 av = *reinterpret_cast<const ex8*>(lds + tap_table[(tap * RT + rt) * 64 + lane]);
 #pragma unroll
-                    for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(bw[tap][j], av, acc[rt][j]);
+                        for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(bw[tap][j], av, acc[rt][j]);
+                    }
                 }
             }
         }
-        for (int tap = 0; tap < (one_chunk ? 0 : TAPS); tap++) {
-            int abase[RT];
+        if constexpr (SP) {
+            const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_in_lo), 0, TAPS * a.kc_in * 16 * 1024, 0x00020000);
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
-            for (int kc = 0; kc < a.kc_in; kc++) {
-                ex8 b[RN];
+            for (int j = 0; j < RN; j++)
 #pragma unroll
-                for (int j = 0; j < RN; j++)
-                    b[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, ((tap * a.kc_in + kc) * 16 + ct0 + j) * 1024, 0));
+                for (int rt = 0; rt < RT; rt++) accc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tap = 0; tap < TAPS; tap++) {
+                int abase[RT];
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    const ex8 av = *reinterpret_cast<const ex8*>(lds + abase[rt] + kc * PLANE);
+                for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
+                for (int kc = 0; kc < a.kc_in; kc++) {
+                    ex8 bh[RN], bl[RN];
 #pragma unroll
-                    for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(b[j], av, acc[rt][j]);
+                    for (int j = 0; j < RN; j++) {
+                        const int fo = ((tap * a.kc_in + kc) * 16 + ct0 + j) * 1024;
+                        bh[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, fo, 0));
+                        bl[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rsl, lane16, fo, 0));
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const ex8 avh = *reinterpret_cast<const ex8*>(lds + abase[rt] + kc * PLANE);
+                        const ex8 avl = *reinterpret_cast<const ex8*>(lds + abase[rt] + kc * PLANE + LO);
+#pragma unroll
+                        for (int j = 0; j < RN; j++) {
+                            acc[rt][j] = Elem<ET>::mfma(bh[j], avh, acc[rt][j]);
+                            accc[rt][j] = Elem<ET>::mfma(bl[j], avh, accc[rt][j]);
+                            accc[rt][j] = Elem<ET>::mfma(bh[j], avl, accc[rt][j]);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int tap = 0; tap < (one_chunk ? 0 : TAPS); tap++) {
+                int abase[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
+                for (int kc = 0; kc < a.kc_in; kc++) {
+                    ex8 b[RN];
+#pragma unroll
+                    for (int j = 0; j < RN; j++)
+                        b[j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, ((tap * a.kc_in + kc) * 16 + ct0 + j) * 1024, 0));
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        const ex8 av = *reinterpret_cast<const ex8*>(lds + abase[rt] + kc * PLANE);
+#pragma unroll
+                        for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(b[j], av, acc[rt][j]);
+                    }
                 }
             }
         }
@@ -1343,14 +1503,26 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         for (int j = 0; j < RN; j++)
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                ex4 pk;
+                ex4 pk, pl;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
+                for (int k = 0; k < 4; k++) {
+                    if constexpr (SP) {
+                        const float v = acc[rt][j][k] + accc[rt][j][k] * SPLIT_INV;
+                        _Float16 h, l;
+                        split_halves(v > 0.f ? v : 0.f, h, l);
+                        pk[k] = h;
+                        pl[k] = l;
+                    } else {
+                        pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
+                    }
+                }
                 *reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = pk;
+                if constexpr (SP) *reinterpret_cast<ex4*>(lds + LO + obase[j] + rt * 16 * LDS_ROWB) = pl;
             }
     }
     // ---- residual tower
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? a.w_lo : a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
     for (int layer = 0; layer < a.nlayers; layer++) {
         if ((layer & 1) == 0) {
 #pragma unroll
@@ -1360,13 +1532,27 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 for (int rt = 0; rt < RT; rt++) acc[rt][j] = b4;
             }
         }
+        if constexpr (SP) {
+#pragma unroll
+            for (int j = 0; j < RN; j++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) accc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
-        auto wl = [&](int tap, int kc, int j) -> ex8 {
-            const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
-            return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
-        };
-        if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET>(lds, tap_table, lane, acc, wl);
-        else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
+        if constexpr (SP) {
+            auto wl2 = [&](int tap, int kc, int j, int part) -> ex8 {
+                const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
+                return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(part ? wrsrc_lo : wrsrc, lane16, frag * 1024, 0));
+            };
+            k_loop_split<NB, P, PERM, RN, PLANE>(lds, tap_table, lane, acc, accc, wl2);
+        } else {
+            auto wl = [&](int tap, int kc, int j) -> ex8 {
+                const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
+                return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
+            };
+            if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET>(lds, tap_table, lane, acc, wl);
+            else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
+        }
         __syncthreads();
         const bool to_second = (layer & 1) == 0;
 #pragma unroll
@@ -1377,14 +1563,34 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int rt = 0; rt < RT; rt++) {
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
+                if constexpr (SP) {
+                    ex4* slot_lo = reinterpret_cast<ex4*>(lds + LO + obase[j] + rt * 16 * LDS_ROWB);
+                    ex4 pl;
 #pragma unroll
-                for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
-                if (to_second) {
-                    const ex4 xv = *slot;
+                    for (int k = 0; k < 4; k++) {
+                        const float v = acc[rt][j][k] + accc[rt][j][k] * SPLIT_INV;
+                        _Float16 h, l;
+                        split_halves(v > 0.f ? v : 0.f, h, l);
+                        pk[k] = h;
+                        pl[k] = l;
+                    }
+                    if (to_second) {
+                        const ex4 xv = *slot, xl = *slot_lo;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
+                        for (int k = 0; k < 4; k++) acc[rt][j][k] = ((float)xv[k] + (float)xl[k] * SPLIT_INV) + b4[k];
+                    }
+                    *slot = pk;
+                    *slot_lo = pl;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pk[k] = Elem<ET>::relu_cvt(acc[rt][j][k]);
+                    if (to_second) {
+                        const ex4 xv = *slot;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc[rt][j][k] = (float)xv[k] + b4[k];
+                    }
+                    *slot = pk;
                 }
-                *slot = pk;
             }
         }
     }
@@ -1411,13 +1617,22 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
 #pragma unroll
             for (int u = 0; u < HU; u++) {
                 const int row = min(row0 + 8 * u, HROWS - 1);
-                const ex4 xv = *reinterpret_cast<const ex4*>(lds + hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8);
+                const int haddr = hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8;
+                const ex4 xv = *reinterpret_cast<const ex4*>(lds + haddr);
+                float xf[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) xf[k] = (float)xv[k];
+                if constexpr (SP) {
+                    const ex4 xl = *reinterpret_cast<const ex4*>(lds + LO + haddr);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xf[k] += (float)xl[k] * SPLIT_INV;
+                }
                 dv[u] = 0.f;
                 du[u] = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    dv[u] += (float)xv[k] * wv[k];
-                    du[u] += (float)xv[k] * wu[k];
+                    dv[u] += xf[k] * wv[k];
+                    du[u] += xf[k] * wu[k];
                 }
             }
 #pragma unroll
@@ -1471,12 +1686,32 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) pacc[rt][j] = b4;
         }
-        auto wlp = [&](int tap, int kc, int j) -> ex8 {
-            const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
-            return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
-        };
-        if constexpr (PERM) k_loop_256_skip<NB, P, RNP, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
-        else k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+        if constexpr (SP) {
+            const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_pol_lo), 0, TAPS * 8 * 8 * RNP * 1024, 0x00020000);
+            f32x4 paccc[RT][RNP];
+#pragma unroll
+            for (int j = 0; j < RNP; j++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) paccc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto wlp2 = [&](int tap, int kc, int j, int part) -> ex8 {
+                const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
+                return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(part ? rsl : rs, lane16, frag * 1024, 0));
+            };
+            k_loop_split<NB, P, PERM, RNP, PLANE>(lds, tap_table, lane, pacc, paccc, wlp2);
+#pragma unroll
+            for (int j = 0; j < RNP; j++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pacc[rt][j][k] += paccc[rt][j][k] * SPLIT_INV;
+        } else {
+            auto wlp = [&](int tap, int kc, int j) -> ex8 {
+                const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
+                return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
+            };
+            if constexpr (PERM) k_loop_256_skip<NB, P, RNP, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+            else k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+        }
 #pragma unroll
         for (int j = 0; j < RNP; j++) {
             const int cbase = (ctp + j) * 16 + q * 4;
@@ -1743,6 +1978,10 @@ uint16_t f2h(float f) {  // IEEE binary16, round to nearest even (host clang has
     return u;
 }
 
+// TZ_PREC_F16X2 runs the fp16 kernels everywhere (RND side networks included) except in the fused trunk + heads launch,
+// where every operand is a hi / lo pair of halves (k_loop_split)
+inline bool prec_is_f16(int precision) { return precision == TZ_PREC_F16 || precision == TZ_PREC_F16X2; }
+
 struct Tensor {
     std::vector<uint32_t> dims;
     const float* data;
@@ -1806,7 +2045,7 @@ int upload(const std::vector<T>& h, T** dev) {
 // in_perm (optional): source input index for each of my input indices.
 int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const std::vector<float>& w,
                 const std::vector<float>& scale, const std::vector<float>& bias, const std::vector<int>* in_perm,
-                ConvW* L) {
+                ConvW* L, bool with_lo = false) {
     L->taps = taps;
     L->cin = cin;
     L->cin_pad = (cin + 31) / 32 * 32;
@@ -1822,7 +2061,8 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
     if (rc) return rc;
     if (precision != TZ_PREC_F32) {
         const int kc_total = L->cin_pad / 32, ct_total = L->cout_pad / 16;
-        std::vector<uint16_t> p((size_t)taps * kc_total * ct_total * 64 * 8, 0);
+        std::vector<uint16_t> p((size_t)taps * kc_total * ct_total * 64 * 8, 0), plo;
+        if (with_lo) plo.assign(p.size(), 0);
         for (int t = 0; t < taps; t++)
             for (int kc = 0; kc < kc_total; kc++)
                 for (int ct = 0; ct < ct_total; ct++)
@@ -1834,11 +2074,17 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
                             if (ci >= cin) continue;
                             const float wv = W(co, ci, t);
                             // fp16 storage: a (BatchNorm-folded) weight beyond the largest finite half would become inf
-                            if (precision == TZ_PREC_F16 && !(wv >= -65504.0f && wv <= 65504.0f))
+                            if (prec_is_f16(precision) && !(wv >= -65504.0f && wv <= 65504.0f))
                                 return tz_fail(TZ_ENUMERIC, "weights: a folded weight is outside fp16's range (or not finite); load this model with TZ_PREC_BF16");
-                            p[((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j] = precision == TZ_PREC_F16 ? f2h(wv) : f2bf(wv);
+                            const size_t at = ((((size_t)t * kc_total + kc) * ct_total + ct) * 64 + lane) * 8 + j;
+                            p[at] = prec_is_f16(precision) ? f2h(wv) : f2bf(wv);
+                            if (with_lo) {   // lo half of the split-precision pair: (w - hi) * 2^11, |lo| <= |w|
+                                const _Float16 hi = (_Float16)wv;
+                                plo[at] = f2h((wv - (float)hi) * 2048.0f);
+                            }
                         }
                     }
+        if (with_lo && (rc = upload(plo, &L->w_lo))) return rc;
         return upload(p, &L->w_mfma);
     }
     std::vector<float> f((size_t)taps * cin * cout);
@@ -1850,6 +2096,7 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
 
 void free_layer(ConvW* L) {
     if (L->w_mfma) (void)hipFree(L->w_mfma);
+    if (L->w_lo) (void)hipFree(L->w_lo);
     if (L->w_f32) (void)hipFree(L->w_f32);
     if (L->bias) (void)hipFree(L->bias);
     *L = ConvW();
@@ -1876,6 +2123,7 @@ struct NetWeights {  // everything tz_net_load_weights replaces, so a failed loa
     ConvW conv_in, policy;
     std::vector<ConvW> res;
     uint16_t* tower_w = nullptr;
+    uint16_t* tower_w_lo = nullptr;
     float* tower_bias = nullptr;
     float* heads = nullptr;
     ConvW rnd[2][3];
@@ -1891,8 +2139,10 @@ void free_weights(NetWeights& w) {
     for (auto& l : w.res) free_layer(&l);
     w.res.clear();
     if (w.tower_w) (void)hipFree(w.tower_w);
+    if (w.tower_w_lo) (void)hipFree(w.tower_w_lo);
     if (w.tower_bias) (void)hipFree(w.tower_bias);
     w.tower_w = nullptr;
+    w.tower_w_lo = nullptr;
     w.tower_bias = nullptr;
     if (w.heads) (void)hipFree(w.heads);
     w.heads = nullptr;
@@ -1914,27 +2164,30 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
     int rc;
     if ((rc = get_tensor(m, "core.input_conv2d.weight", (size_t)FILTERS * cin * 9, w))) return rc;
     if ((rc = bn_fold(m, "core.batch_norm", FILTERS, scale, bias))) return rc;
-    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in))) return rc;
+    const bool split = prec == TZ_PREC_F16X2;
+    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in, split))) return rc;
     W.res.resize(2 * net->blocks);
     for (int b = 0; b < net->blocks; b++)
         for (int h = 0; h < 2; h++) {
             const std::string p = "core.res_block_" + std::to_string(b) + (h ? ".b" : ".a");
             if ((rc = get_tensor(m, p + ".conv2d.weight", (size_t)FILTERS * FILTERS * 9, w))) return rc;
             if ((rc = bn_fold(m, p + ".batch_norm", FILTERS, scale, bias))) return rc;
-            if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h]))) return rc;
+            if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h], split))) return rc;
         }
     if (prec != TZ_PREC_F32 && net->blocks > 0) {  // the fused tower kernel reads all layers from one buffer
         const size_t layer_elems = (size_t)9 * 8 * 16 * 64 * 8, nl = W.res.size();
         TZ_HIP(hipMalloc(&W.tower_w, nl * layer_elems * 2));
+        if (split) TZ_HIP(hipMalloc(&W.tower_w_lo, nl * layer_elems * 2));
         TZ_HIP(hipMalloc(&W.tower_bias, nl * FILTERS * sizeof(float)));
         for (size_t l = 0; l < nl; l++) {
             TZ_HIP(hipMemcpy(W.tower_w + l * layer_elems, W.res[l].w_mfma, layer_elems * 2, hipMemcpyDeviceToDevice));
+            if (split) TZ_HIP(hipMemcpy(W.tower_w_lo + l * layer_elems, W.res[l].w_lo, layer_elems * 2, hipMemcpyDeviceToDevice));
             TZ_HIP(hipMemcpy(W.tower_bias + l * FILTERS, W.res[l].bias, FILTERS * sizeof(float), hipMemcpyDeviceToDevice));
         }
     }
     if ((rc = get_tensor(m, "policy.conv2d.weight", (size_t)net->pol_ch * FILTERS * 9, w))) return rc;
     if ((rc = get_tensor(m, "policy.conv2d.bias", net->pol_ch, bias))) return rc;
-    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy))) return rc;
+    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy, split))) return rc;
     // heads
     std::vector<float> hv, hu, lv, lu, t1;
     if ((rc = get_tensor(m, "value.conv2d.weight", FILTERS, hv))) return rc;
@@ -2064,7 +2317,7 @@ int linear_grouped_bf16(int precision, const uint16_t* w, const float* bias, int
     a.w_z_frags = a.kc_total * a.ct_total;
     a.bias_z = cout_pad;
     a.out_z = out_z;
-    if (precision == TZ_PREC_F16) return launch_conv<1, 128, 8, 2, 1, false, false, 0, 1, _Float16>(a, max_positions, cout_pad / 256, st);
+    if (prec_is_f16(precision)) return launch_conv<1, 128, 8, 2, 1, false, false, 0, 1, _Float16>(a, max_positions, cout_pad / 256, st);
     return launch_conv<1, 128, 8, 2, 1, false, false>(a, max_positions, cout_pad / 256, st);
 }
 
@@ -2120,7 +2373,7 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     a.in_stride = L.cin_pad;
     a.groups = 1;
     a.in_z = a.w_z_frags = a.bias_z = a.out_z = 0;
-    if (net->precision == TZ_PREC_F16) return conv_dispatch<_Float16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
+    if (prec_is_f16(net->precision)) return conv_dispatch<_Float16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
     return conv_dispatch<__bf16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
 }
 
@@ -2172,7 +2425,7 @@ int tower_bf16(tz_net* net, const void* in, void* out, const int32_t* count_dev,
     a.count_dev = count_dev;
     a.count_host = count_host;
     a.nlayers = 2 * net->blocks;
-    const bool h = net->precision == TZ_PREC_F16;
+    const bool h = prec_is_f16(net->precision);
     switch (net->n) {
         // OPT 4224 = tap table in LDS + pinned issue order: the loop the net kernel ships (see tz_debug_tower_bench)
         case 3: return h ? launch_tower<3, 4224, _Float16>(a, max_positions, st) : launch_tower<3, 4224>(a, max_positions, st);
@@ -2192,11 +2445,12 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB)>
+template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
-    const size_t smem = (size_t)LROWS * LDS_ROWB * 8 + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
-    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM>;
+    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
+    static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
+    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
     int attr_dev = 0;
     TZ_HIP(hipGetDevice(&attr_dev));
@@ -2283,6 +2537,20 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     if (net_fused_writes_rnd_input(net)) {   // the fused kernel also writes the RND networks' normalised input
         a.rnd_in = net->rnd_in;
         a.rnd_stride = net->cin * net->nn;
+    }
+    a.w_in_lo = net->conv_in.w_lo;
+    a.w_lo = net->tower_w_lo;
+    a.w_pol_lo = net->policy.w_lo;
+    if (net->precision == TZ_PREC_F16X2) {
+        // split precision: hi and lo planes share the 160 KB, so half the boards per workgroup (5x5: 4 boards, square-major
+        // rows, 14 of 63 (tap, tile) pairs skipped; the other sizes board-major)
+        switch (net->n) {
+            case 3: return launch_net<3, 1, _Float16, false, 8, 1>(a, max_positions, st);
+            case 4: return launch_net<4, 1, _Float16, false, 6, 1>(a, max_positions, st);
+            case 5: return launch_net<5, 1, _Float16, true, 4, 1>(a, max_positions, st);
+            case 6: return launch_net<6, 2, _Float16, false, 2, 1>(a, max_positions, st);
+        }
+        return tz_fail(TZ_EINVAL, "net: unsupported board size");
     }
     if (net->precision == TZ_PREC_F16) return net_fused_et<_Float16>(net, a, max_positions, st);
     return net_fused_et<__bf16>(net, a, max_positions, st);
@@ -2389,7 +2657,9 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     const bool need_planes = !bf || net->has_hash;
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
-    if (bf && net->blocks > 0 && net->tower_w && net_fused_mode() == 2) {
+    const bool split = net->precision == TZ_PREC_F16X2;
+    if (split && !(net->blocks > 0 && net->tower_w_lo)) return tz_fail(TZ_EINVAL, "forward: TZ_PREC_F16X2 needs a network with at least one residual block");
+    if (bf && net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split)) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (net->profile) {
             TZ_HIP(hipEventCreate(&e0));
@@ -2446,7 +2716,7 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         if ((rc = conv_bf16(net, net->policy, x, nullptr, nullptr, count_dev, count_host, max_positions, nullptr,
                             net->policy_out, net->pol_stride, false, true, true, st)))
             return rc;
-        if (net->precision == TZ_PREC_F16)
+        if (prec_is_f16(net->precision))
             heads_kernel<_Float16><<<max_positions, 64, 0, st>>>((const _Float16*)x, net->heads, count_dev, count_host, nn, net->value, net->ube);
         else
             heads_kernel<__bf16><<<max_positions, 64, 0, st>>>((const __bf16*)x, net->heads, count_dev, count_host, nn, net->value, net->ube);
@@ -2476,11 +2746,11 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         if (bf) {
             // 3 launches: input planes straight from the packed states, layer 1 of both nets as one GEMM,
             // layers 2 and 3 as grouped launches (blockIdx.z = net)
-            const bool fused_wrote_it = net->blocks > 0 && net->tower_w && net_fused_mode() == 2 && net_fused_writes_rnd_input(net);
+            const bool fused_wrote_it = net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split) && net_fused_writes_rnd_input(net);
             switch (net->n) {
                 case 5:
                     if (fused_wrote_it) break;   // net_mfma_kernel wrote x / sum(x^2) while it built the planes
-                    if (net->precision == TZ_PREC_F16)
+                    if (prec_is_f16(net->precision))
                         rnd_prep_state_kernel<5, _Float16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (_Float16*)net->rnd_in);
                     else
                         rnd_prep_state_kernel<5, __bf16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (__bf16*)net->rnd_in);
@@ -2550,7 +2820,7 @@ int tz_net_create(int board_n, int arch, int device_id, int precision, int block
     else if (arch != TZ_ARCH_TEST) return tz_fail(TZ_EINVAL, "tz_net_create: unknown architecture");
     if (board_n && board_n != n) return tz_fail(TZ_EINVAL, "tz_net_create: board size does not match the architecture");
     if (n < 3 || n > 6) return tz_fail(TZ_EINVAL, "tz_net_create: board size must be 3..6");
-    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16)
+    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16 && precision != TZ_PREC_F16X2)
         return tz_fail(TZ_EINVAL, "tz_net_create: bad precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -2603,6 +2873,7 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     old.policy = net->policy;
     old.res = net->res;
     old.tower_w = net->tower_w;
+    old.tower_w_lo = net->tower_w_lo;
     old.tower_bias = net->tower_bias;
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)
@@ -2618,6 +2889,7 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     net->policy = W.policy;
     net->res = W.res;
     net->tower_w = W.tower_w;
+    net->tower_w_lo = W.tower_w_lo;
     net->tower_bias = W.tower_bias;
     net->heads = W.heads;
     for (int a = 0; a < 2; a++)
@@ -2821,6 +3093,7 @@ int tz_net_destroy(tz_net* net) {
     old.policy = net->policy;
     old.res = net->res;
     old.tower_w = net->tower_w;
+    old.tower_w_lo = net->tower_w_lo;
     old.tower_bias = net->tower_bias;
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)

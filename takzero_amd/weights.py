@@ -141,3 +141,15 @@ def init_weights(arch, n=0, blocks=0, seed=123, trained_stats=False):
         # simhash_matrix: root.var("simhash_matrix", [in_size, 32], Init::Randn{0,1}) net6_simhash.rs:133-137
         t["simhash_matrix"] = rng.normal(0.0, 1.0, size=(cin * nn, HASH_BITS)).astype(np.float32)
     return t
+
+
+def rescale_heads(tensors, policy_gain=1.0, value_gain=1.0, ube_gain=1.0):
+    """A copy of `tensors` whose policy logits, value pre-activation (before tanh) and UBE output are multiplied by the
+    given gains (the heads are linear in their last layer).  Random-init logits are ~0.2 in magnitude; a trained
+    net5 emits logits of order 5-10, which is where an absolute 1e-3 tolerance has to be demonstrated: the tests and
+    bench.py bring a random-init net to that scale with this function."""
+    out = dict(tensors)
+    for name, gain in (("policy.conv2d", policy_gain), ("value.linear", value_gain), ("ube.linear", ube_gain)):
+        for part in (".weight", ".bias"):
+            out[name + part] = (np.asarray(tensors[name + part], np.float32) * np.float32(gain)).astype(np.float32)
+    return out

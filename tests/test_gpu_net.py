@@ -12,12 +12,18 @@ from gpu_util import random_positions, require_gpu
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
-# north_star: policy/value logits within 1e-3 of the fp32 LibTorch path.  That is the bar for the default MFMA path
-# (fp16 storage, fp32 accumulate: measured <= 1.5e-4) and for the fp32 validation path.  The optional bf16 storage
-# (TZ_PRECISION=bf16, the same kernels, 5 % faster) cannot meet it through 41 stacked convs - one bf16 rounding is
-# already 2e-3 relative - and is held to the absolute bounds below (measured: logits <= 6.8e-3, value <= 2.4e-3).
+# north_star: policy/value logits within 1e-3 (absolute) of the fp32 LibTorch path.  A random-init net5 emits logits of
+# magnitude ~0.2, a trained one 5-10, so the bar is demonstrated on weights brought to that scale (`_trained_scale`).
+#   TZ_PREC_F32   plain-FMA validation path: 1e-3 at any scale (measured ~1e-6 relative)
+#   TZ_PREC_F16X2 split precision (hi/lo fp16 operands, 3 MFMAs per product): 1e-3 at trained scale - the mode that meets
+#                 the north star's tolerance on the MFMA path
+#   TZ_PREC_F16   throughput default (fp16 storage, fp32 accumulate): ~2e-4 relative; 1e-3 absolute only while |logit| <~ 1,
+#                 held to a relative bound at trained scale (F16_REL_TOL) and reported
+#   TZ_PREC_BF16  same kernels, 5 % faster: explicit absolute bounds at random-init scale
 F32_TOL = 1e-3
 BF16_LOGIT_TOL, BF16_VALUE_TOL = 1.2e-2, 5e-3
+F16_REL_TOL = 2e-3          # max |delta logit| / max |logit| of the fp16 default at trained scale (measured 1.0e-3)
+TRAINED_LOGIT = 8.0         # target max |logit| of the rescaled nets (a trained net5: 5-10)
 
 
 def _planes(oracle, states):
@@ -37,7 +43,20 @@ def test_encoder_matches_game_repr(oracle, n):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def _compare(A, oracle, arch, n, blocks, prec, batch, seed, trained):
+def _trained_scale(w, planes, blocks):
+    """Heads rescaled so that the fp32 torch graph emits max |logit| = TRAINED_LOGIT, a value pre-activation of +-1.5
+    (tanh still sensitive) and |ube| up to 2 on these positions: the output scale of a trained net."""
+    import nets_torch as T
+    import torch
+    from takzero_amd import weights as W
+
+    pol, val, ube = T.forward(w, planes, blocks)
+    pre = torch.atanh(val.clamp(-0.999999, 0.999999))
+    return W.rescale_heads(w, TRAINED_LOGIT / float(pol.abs().max()), 1.5 / max(1e-6, float(pre.abs().max())),
+                           2.0 / max(1e-6, float(ube.abs().max())))
+
+
+def _compare(A, oracle, arch, n, blocks, prec, batch, seed, trained, trained_scale=False):
     import nets_torch as T
     from takzero_amd import weights as W
 
@@ -46,6 +65,8 @@ def _compare(A, oracle, arch, n, blocks, prec, batch, seed, trained):
     blocks = W.arch_blocks(arch, blocks)
     states = random_positions(oracle, O, n, 4, batch, seed, max_ply=40)
     planes = _planes(oracle, states).reshape(batch, -1, n, n)
+    if trained_scale:
+        w = _trained_scale(w, planes, blocks)
     pol_t, val_t, ube_t = T.forward(w, planes, blocks)
     var_t = T.variance(w, planes, ube_t, arch if arch != W.ARCH_TEST else 0).numpy()
     pol_t = pol_t.reshape(batch, -1).numpy()
@@ -61,7 +82,7 @@ def _compare(A, oracle, arch, n, blocks, prec, batch, seed, trained):
     assert np.array_equal(val, val2)
     err = dict(policy=np.abs(pol - pol_t).max(), value=np.abs(val - val_t.numpy()).max(),
                ube=np.abs(ube - ube_t.numpy()).max(), variance=np.abs(var - var_t).max(),
-               scale=np.abs(pol_t).max())
+               scale=np.abs(pol_t).max(), value_scale=np.abs(val_t.numpy()).max(), ube_scale=np.abs(ube_t.numpy()).max())
     net.close()
     return err
 
@@ -84,14 +105,47 @@ def test_bf16_mfma_path_close_to_torch(oracle, arch, n, blocks, batch):
     assert err["policy"] < BF16_LOGIT_TOL and err["value"] < BF16_VALUE_TOL and err["ube"] < BF16_VALUE_TOL
 
 
-@pytest.mark.parametrize("arch,n,blocks,batch", [(5, 5, 20, 21), (100, 5, 3, 19), (6, 6, 16, 7), (4, 4, 16, 15), (100, 3, 2, 33)])
-def test_f16_mfma_path_within_1e_3_of_torch(oracle, arch, n, blocks, batch):
-    """TZ_PREC_F16, the default: the MFMA kernels with IEEE fp16 storage meet the north star's 1e-3 logit/value tolerance
-    against the fp32 LibTorch graph, on the full nets."""
+NETS = [(5, 5, 20, 21), (100, 5, 3, 19), (6, 6, 16, 7), (4, 4, 16, 15), (100, 3, 2, 33)]
+
+
+@pytest.mark.parametrize("arch,n,blocks,batch", NETS)
+def test_f16_mfma_path_within_1e_3_of_torch_at_random_init_scale(oracle, arch, n, blocks, batch):
+    """TZ_PREC_F16 on random-init weights (|logit| ~ 0.2, the weights bench.py runs): within 1e-3 absolute.  This says
+    ~1e-3 *relative*; the trained-scale cases below are the ones that carry the north star's tolerance."""
     A = require_gpu()
     err = _compare(A, oracle, arch, n, blocks, A.PREC_F16, batch, 44, False)
-    print("f16 errors", err)
+    print("f16 errors (random-init scale)", err)
     assert err["policy"] < F32_TOL and err["value"] < F32_TOL and err["ube"] < 2 * F32_TOL
+
+
+@pytest.mark.parametrize("arch,n,blocks,batch", NETS)
+def test_f16x2_split_precision_within_1e_3_of_torch_at_trained_logit_scale(oracle, arch, n, blocks, batch):
+    """TZ_PREC_F16X2 with BatchNorm statistics of a trained net and heads at a trained net's output scale (max |logit| = 8,
+    value pre-activation 1.5, |ube| 2): policy, value and UBE within the north star's absolute 1e-3 of the fp32 LibTorch
+    graph (net5.rs:184-191,237-238) on the full nets of every board size."""
+    A = require_gpu()
+    err = _compare(A, oracle, arch, n, blocks, A.PREC_F16X2, batch, 45, True, trained_scale=True)
+    print("f16x2 errors (trained scale)", err)
+    assert 7.9 < err["scale"] < 8.1
+    assert err["policy"] < F32_TOL and err["value"] < F32_TOL and err["ube"] < F32_TOL
+
+
+@pytest.mark.parametrize("arch,n,blocks,batch", NETS)
+def test_f16_default_at_trained_logit_scale_is_relative(oracle, arch, n, blocks, batch):
+    """The fp16 throughput default on the same trained-scale weights: its error is relative (~2e-4 of the logit scale
+    per 41 convs), so at |logit| = 8 it does NOT meet 1e-3 absolute (measured 8e-3 on net5); it is held to 2e-3 of the
+    logit scale and the figure is printed (Precision; profiles/r02_precision.json)."""
+    A = require_gpu()
+    err = _compare(A, oracle, arch, n, blocks, A.PREC_F16, batch, 45, True, trained_scale=True)
+    print("f16 errors (trained scale)", err)
+    assert err["policy"] < F16_REL_TOL * err["scale"] and err["value"] < 5e-3 and err["ube"] < 2 * F16_REL_TOL * max(2.0, err["ube_scale"])
+
+
+def test_f32_path_at_trained_logit_scale(oracle):
+    A = require_gpu()
+    err = _compare(A, oracle, 5, 5, 20, A.PREC_F32, 10, 45, True, trained_scale=True)
+    print("f32 errors (trained scale)", err)
+    assert err["policy"] < 1e-4 and err["value"] < 1e-4 and err["ube"] < 1e-4
 
 
 def test_forward_is_batch_composition_independent(oracle):
