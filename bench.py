@@ -11,9 +11,13 @@ subtree-reuse step, restart of finished games, target completion.  Everything a 
 (tree descent, move generation, plane encoding, the net forward, expansion, backup) runs on the GPU with
 positions resident in HBM; per move the host only draws the Dirichlet noise and reads root statistics.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), independent shards of 4096 games
-(weak scaling), and after every move an all-gather of the finished games' target records — the only
-collective on the path.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, for the barriers and the final reduction of the
+counters), independent shards of 4096 games (weak scaling), and after every move the hand-over of the finished games'
+packed target records and replay lines — an all-gather of counts, then of the padded records — the only collective
+on the path; by default through the library's own RCCL communicator (tz_comm_*, ncclAllGather on the shard's GPU;
+TZ_BENCH_EXCHANGE=torch runs it through torch.distributed instead).  The JSON line names the backend, the world size
+and the transport; if RCCL cannot form the ring the run ends with a non-zero exit code (no silent fallback;
+TZ_BENCH_BACKEND=gloo is an explicit rehearsal switch).
 
 Prints ONE JSON line (rank 0).  `value` = MCTS simulations/s summed over all ranks.
 """
@@ -100,6 +104,45 @@ def cpu_baseline(seconds=12.0):
                        % (steps, dt))
 
 
+def precision_report(A, SP, W, args, primary_sims_per_s, moves=2):
+    """Throughput of the precision the main measurement did not run (same workload, `moves` timed moves after one warm-up
+    move) and the measured output errors of both against the library's fp32 path at random-init and at trained logit scale
+    (takzero_amd/precision.py).  The north star's tolerance (logits within 1e-3 of the fp32 path) is met by f16x2 at any
+    scale and by f16 only while |logit| <~ 1."""
+    from takzero_amd import precision as P
+
+    other = "f16x2" if args.precision == "f16" else "f16"
+    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_NAMES[other])
+    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
+    mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
+    sp = SP.NativeSelfPlay(mcts, args.sims, seed=0, shard=0, search=args.search, sampled_actions=64)
+    sp.play_move()
+    mcts.sync()
+    s0 = mcts.counters()[0]
+    t0 = time.perf_counter()
+    for _ in range(moves):
+        sp.play_move()
+    mcts.sync()
+    dt = time.perf_counter() - t0
+    rate = (mcts.counters()[0] - s0) / dt
+    sp.close()
+    mcts.close()
+    net.close()
+    states = P.sample_positions(N_BOARD, HALF_KOMI, 64, seed=7)
+    w0 = W.init_weights(W.ARCH_NET5, seed=123)
+    e0 = P.errors_against_f32(A.ARCH_NET5, w0, states, precisions=("f16", "f16x2"))
+    e1 = P.errors_against_f32(A.ARCH_NET5, P.trained_scale_weights(A.ARCH_NET5, states, seed=123), states, precisions=("f16", "f16x2"))
+    rates = {args.precision: primary_sims_per_s, other: rate}
+    out = {"reference": e0["reference"], "positions": e0["positions"], "tolerance": "north star: logits within 1e-3 (absolute) of the fp32 path",
+           "timed_moves_of_the_second_precision": moves}
+    for p in ("f16", "f16x2"):
+        out[p] = {"sims_per_s": rates[p],
+                  "random_init_scale": dict(e0[p], logit_scale=e0["logit_scale"]),
+                  "trained_scale": dict(e1[p], logit_scale=e1["logit_scale"]),
+                  "meets_1e-3_at_trained_scale": bool(e1[p]["max_abs_logit_err"] < 1e-3 and e1[p]["max_abs_value_err"] < 1e-3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,9 +159,12 @@ def main():
     ap.add_argument("--driver", choices=["native", "python"], default="native",
                     help="native = the self-play outer loop in csrc/tz_host.cpp (tz_selfplay_*); python = its mirror in "
                          "takzero_amd/selfplay.py")
-    ap.add_argument("--precision", choices=["bf16", "f16"], default=os.environ.get("TZ_PRECISION", "f16"),
-                    help="16-bit storage type of the MFMA path (same kernels): f16 (default) keeps logits within 1e-3 of the fp32 "
-                         "graph, bf16 is 5 %% faster and lands at 1e-3 .. 7e-3")
+    ap.add_argument("--precision", choices=["bf16", "f16", "f16x2"], default=os.environ.get("TZ_PRECISION", "f16"),
+                    help="arithmetic of the MFMA path: f16 (default) = fp16 storage, fp32 accumulate, ~2e-4 relative logit error; "
+                         "f16x2 = split precision (hi/lo fp16 operands, 3 MFMAs per product), within 1e-3 absolute at trained logit "
+                         "scale, ~3x the MFMA work; bf16 = the f16 kernels 5 %% faster at 1e-3 .. 7e-3 (random-init scale)")
+    ap.add_argument("--no-precision-report", action="store_true",
+                    help="skip the second measurement (N = 1 only): throughput of the other precision and the measured logit errors")
     args = ap.parse_args()
     if args.sims is None:
         args.sims = 768 if args.search == "gumbel" else SIMS
@@ -139,7 +185,7 @@ def main():
     import torch
 
     dist = None
-    backend = os.environ.get("TZ_BENCH_BACKEND", "nccl")   # "gloo" + TZ_BENCH_DEVICE=0: rehearsal of N ranks on one GPU
+    backend = os.environ.get("TZ_BENCH_BACKEND", "nccl")   # "gloo" (+ TZ_BENCH_DEVICE=0): explicit rehearsal of N ranks without RCCL
     if "TZ_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["TZ_BENCH_DEVICE"])
     if world > 1:
@@ -150,22 +196,21 @@ def main():
             try:
                 torch.cuda.set_device(local_rank)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.zeros(1, device="cuda:%d" % local_rank)
+                probe = torch.ones(1, device="cuda:%d" % local_rank)
                 dist.all_reduce(probe)          # fail here, not in the timed region, if RCCL cannot form the ring
                 torch.cuda.synchronize()
-            except Exception as e:              # the shards are independent: the target exchange can run over gloo
-                sys.stderr.write("rank %d: RCCL unavailable (%r), exchanging targets over gloo\n" % (rank, e))
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo")
+                assert int(probe.item()) == world, "all_reduce over %d ranks returned %r" % (world, probe.item())
+            except Exception as e:              # no fallback: a SCALE record must show what actually ran
+                sys.stderr.write("rank %d: backend nccl (RCCL) requested and unavailable: %r\n" % (rank, e))
+                sys.stderr.flush()
+                os._exit(3)
         else:
             dist.init_process_group(backend)
     import takzero_amd.api as A
     from takzero_amd import selfplay as SP
     from takzero_amd import weights as W
 
-    net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_F16 if args.precision == "f16" else A.PREC_BF16)
+    net = A.Net(arch=A.ARCH_NET5, device=local_rank, precision=A.PREC_NAMES[args.precision])
     net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
     mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
     if args.driver == "native":
@@ -173,6 +218,33 @@ def main():
     else:
         sp = SP.SelfPlay(mcts, args.sims, seed=0, shard=rank, search=args.search, sampled_actions=64)
     dev = "cuda:%d" % local_rank if backend == "nccl" else "cpu"
+    # the hand-over of the finished targets between the shards
+    exchange = os.environ.get("TZ_BENCH_EXCHANGE", "native" if args.driver == "native" else "torch")
+    comm = None
+    if dist is not None and exchange == "native":
+        from takzero_amd import comm as CM
+
+        try:
+            if backend == "nccl":
+                ident = torch.zeros(CM.ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    ident = torch.frombuffer(bytearray(CM.unique_id()), dtype=torch.uint8).to(dev)
+                dist.broadcast(ident, 0)
+                comm = CM.Comm.rccl(bytes(ident.cpu().numpy().tobytes()), rank, world, local_rank)
+            else:                               # rehearsal without RCCL: the same packing over the shared-directory transport
+                box = [None]
+                if rank == 0:
+                    import tempfile
+
+                    box[0] = tempfile.mkdtemp(prefix="tz_bench_xch_")
+                dist.broadcast_object_list(box, 0)
+                comm = CM.Comm.fs(box[0], rank, world)
+            comm.barrier()
+            sp.set_comm(comm, writer_rank=-1)   # every rank ends up with all the lines, as `learn` on any rank would need
+        except Exception as e:
+            sys.stderr.write("rank %d: the native exchange (tz_comm over %s) failed: %r\n" % (rank, backend, e))
+            sys.stderr.flush()
+            os._exit(4)
 
     def barrier():
         mcts.sync()
@@ -185,9 +257,11 @@ def main():
         """One outer-loop iteration + the exchange of the finished targets (every rank ends up with all of them)."""
         if args.driver == "native":
             sp.play_move()
+            if comm is not None:
+                sp.exchange()                # all-gather of counts + packed records over the library's communicator
             lines = sp.take_text(0)          # target lines finished this move, as learn reads them
             sp.take_text(1)
-            if dist is not None:
+            if dist is not None and comm is None:
                 lines = SP.all_gather_bytes(lines, dev)
             return lines.count(b"\n")
         t, _r = sp.play_move()
@@ -224,6 +298,10 @@ def main():
             "value": sims / dt_max,
             "unit": "sims/s",
             "n_gpus": world,
+            "world": world,
+            "backend": (backend if dist is not None else "none (single process)"),
+            "exchange": ((dict(comm.info(), api="tz_comm (csrc/tz_comm.cpp)") if comm is not None
+                          else {"transport": "torch.distributed " + backend}) if dist is not None else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt_max / max(1, args.steps),
@@ -252,6 +330,9 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "traffic_source": ("stored figure, not measured in this run: profiles/tower_pmc_traffic.json (rocprofv3 --pmc "
+                                                  "passes of the same command; 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction)"
+                                                  if traffic is not None else None),
                                "kernel": KERNEL_NAME,
                                "rows": "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS
                                if FUSED_MODE == 2 else "board-major",
@@ -268,9 +349,23 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the checker must not take the measurement down with it
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_precision_report and args.games == GAMES and args.precision in ("f16", "f16x2"):
+            # the other precision's throughput and both measured errors: close the first engine (66 GB of pools)
+            sp.close()
+            mcts.close()
+            net.close()
+            mcts = net = None
+            try:
+                out["precisions"] = precision_report(A, SP, W, args, out["value"])
+            except Exception as e:
+                out["precisions"] = {"error": repr(e)}
         print(json.dumps(out))
-    mcts.close()
-    net.close()
+    if comm is not None:
+        sp.close()
+        comm.close()
+    if mcts is not None:
+        mcts.close()
+        net.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,10 +1,14 @@
 // selfplay_cli — the reference's `selfplay --directory DIR` as a plain C++ program over the C ABI of libtakzero_hip.so
 // (no Python, no torch): creates the network and the batched search on one GPU and hands control to tz_selfplay_run
-// (selfplay/src/main.rs:63-205).  Weights come from a .tzw container (takzero_amd.weights / takzero_amd.ot convert the
-// reference's .ot files); DIR/model_latest.tzw is re-read whenever it changes (selfplay/src/main.rs:107-121).
+// (selfplay/src/main.rs:63-205).  DIR/model_latest.ot — the LibTorch archive `learn` writes (the reference's, or
+// examples/learn_cli.cpp / tz_learn_run here) — is re-read whenever it changes (selfplay/src/main.rs:107-121); --model names
+// the first model (.ot or .tzw), without it the net starts from Net::new(seed).
+// N shards: --rank R --world N --comm rccl|fs [--comm-dir D] runs one process per GPU (device = rank unless --device);
+// the shards hand over after every move through tz_comm (RCCL all-gather of the packed targets; rank 0 appends everybody's
+// lines to the directory's files) and rank 0's model reloads are broadcast to the others.
 //
 //   g++ -std=c++17 -O2 examples/selfplay_cli.cpp -Iinclude -Ltakzero_amd -ltakzero_hip -Wl,-rpath,$PWD/takzero_amd -o selfplay_cli
-//   ./selfplay_cli --directory DIR --model DIR/model_latest.tzw --arch 5 --games 128 --sims 768 --search gumbel
+//   ./selfplay_cli --directory DIR --arch 5 --games 128 --sims 768 --search gumbel
 #include <sys/stat.h>
 
 #include <chrono>
@@ -18,25 +22,41 @@
 struct Reload {
     tz_net* net;
     std::string path;
+    tz_comm* comm = nullptr;
+    int rank = 0;
     long long stamp_s = -1, stamp_ns = -1, size = -1, inode = -1;
     int reloads = 0;
 };
 
+// rank 0 (or the only process) looks at the file; with a communicator every rank then takes the same branch
 static int reload_model(void* user) {
     Reload* r = static_cast<Reload*>(user);
-    struct stat st;
-    if (stat(r->path.c_str(), &st) != 0) return 0;  // no new model yet: keep playing with the current one
-    if (st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size && (long long)st.st_ino == r->inode)
-        return 0;
-    if (tz_net_load_weights(r->net, r->path.c_str()) != 0) {
-        fprintf(stderr, "Cannot load model: %s, not retrying.\n", tz_last_error());  // the old weights stay active
+    int status = 1;   // 0 = a new model is active on the root
+    if (r->rank == 0) {
+        struct stat st;
+        const bool changed = stat(r->path.c_str(), &st) == 0 &&   // no model yet: keep playing with the current one
+                             !(st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size &&
+                               (long long)st.st_ino == r->inode);
+        if (changed) {
+            if (tz_net_load_weights(r->net, r->path.c_str()) != 0) {
+                fprintf(stderr, "Cannot load model: %s, not retrying.\n", tz_last_error());  // the old weights stay active
+            } else {
+                status = 0;
+            }
+            r->stamp_s = st.st_mtim.tv_sec;   // a file that does not parse is not looked at again until it changes
+            r->stamp_ns = st.st_mtim.tv_nsec;
+            r->size = st.st_size;
+            r->inode = (long long)st.st_ino;
+        }
+    }
+    if (r->comm && tz_net_broadcast(r->net, r->comm, 0, status) != 0) {
+        fprintf(stderr, "tz_net_broadcast: %s\n", tz_last_error());
+        return -1;
+    }
+    if (r->comm && r->rank != 0) {   // learn the branch the root took
         return 0;
     }
-    r->stamp_s = st.st_mtim.tv_sec;
-    r->stamp_ns = st.st_mtim.tv_nsec;
-    r->size = st.st_size;
-    r->inode = (long long)st.st_ino;
-    r->reloads++;
+    if (status == 0) r->reloads++;
     return 0;
 }
 
@@ -49,8 +69,10 @@ static int reload_model(void* user) {
     } while (0)
 
 int main(int argc, char** argv) {
-    std::string directory, model, search = "gumbel";
+    std::string directory, model, search = "gumbel", watch = "model_latest.ot", comm_kind, comm_dir;
     int arch = TZ_ARCH_NET5, n = 5, blocks = 0, games = 128, sims = 768, moves = -1, exploration = 0, k = 64, precision = TZ_PREC_F16;
+    int rank = 0, world = 1, device = -1;
+    unsigned long long seed = 0;
     double wait_limit = -1.0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -66,6 +88,14 @@ int main(int argc, char** argv) {
         else if (a == "--moves") moves = atoi(next());
         else if (a == "--sampled-actions") k = atoi(next());
         else if (a == "--wait-limit") wait_limit = atof(next());
+        else if (a == "--watch") watch = next();
+        else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
+        else if (a == "--rank") rank = atoi(next());
+        else if (a == "--world") world = atoi(next());
+        else if (a == "--device") device = atoi(next());
+        else if (a == "--comm") comm_kind = next();
+        else if (a == "--comm-dir") comm_dir = next();
+        else if (a == "--f16x2") precision = TZ_PREC_F16X2;
         else if (a == "--f16") precision = TZ_PREC_F16;
         else if (a == "--bf16") precision = TZ_PREC_BF16;
         else if (a == "--exploration") exploration = 1;
@@ -74,22 +104,37 @@ int main(int argc, char** argv) {
             return 2;
         }
     }
-    if (directory.empty() || model.empty()) {
-        fprintf(stderr, "usage: selfplay_cli --directory DIR --model FILE.tzw [--arch 4|5|6|100 --n N --blocks K --games B --sims S "
-                        "--search puct|gumbel --sampled-actions K --moves M --exploration --f16 --wait-limit SECONDS]\n");
+    if (directory.empty() || (world > 1 && comm_kind != "rccl" && comm_kind != "fs")) {
+        fprintf(stderr, "usage: selfplay_cli --directory DIR [--model FILE.ot|.tzw --watch model_latest.ot --arch 4|5|6|100 --n N --blocks K "
+                        "--games B --sims S --search puct|gumbel --sampled-actions K --moves M --exploration --f16|--bf16|--f16x2 "
+                        "--wait-limit SECONDS --seed X] [--rank R --world N --comm rccl|fs --comm-dir D --device G]\n");
         return 2;
     }
+    if (device < 0) device = comm_kind == "fs" ? 0 : rank;
+    if (comm_dir.empty()) comm_dir = directory;
     if (arch == TZ_ARCH_NET5) n = 5;
     if (arch == TZ_ARCH_NET4_SIMHASH) n = 4;
     if (arch == TZ_ARCH_NET6_SIMHASH) n = 6;
     tz_net* net = nullptr;
     tz_search* mcts = nullptr;
     tz_selfplay* sp = nullptr;
-    CHECK(tz_net_create(n, arch, 0, precision, blocks, &net));
-    CHECK(tz_net_load_weights(net, model.c_str()));
+    tz_comm* comm = nullptr;
+    CHECK(tz_net_create(n, arch, device, precision, blocks, &net));
+    if (!model.empty()) CHECK(tz_net_load_weights(net, model.c_str()));
+    else CHECK(tz_net_init_random(net, seed));      // Net::new(DEVICE, seed), selfplay/src/main.rs:71 (same seed on every rank)
     CHECK(tz_search_create(net, TZ_AGENT_NET, games, n, 4, 0, &mcts));
-    CHECK(tz_selfplay_create(mcts, sims, 0, 0, search == "puct" ? 0 : 1, k, exploration, &sp));
-    Reload reload{net, directory + "/model_latest.tzw"};
+    CHECK(tz_selfplay_create(mcts, sims, seed, rank, search == "puct" ? 0 : 1, k, exploration, &sp));
+    if (world > 1) {
+        if (comm_kind == "rccl") {
+            unsigned char id[TZ_COMM_ID_BYTES];
+            CHECK(tz_comm_rendezvous_id(comm_dir.c_str(), rank, id, 300.0));
+            CHECK(tz_comm_create_rccl(id, rank, world, device, &comm));
+        } else {
+            CHECK(tz_comm_create_fs(comm_dir.c_str(), rank, world, 600.0, &comm));
+        }
+        CHECK(tz_selfplay_set_comm(sp, comm, 0));
+    }
+    Reload reload{net, directory + "/" + watch, comm, rank};
     const auto t0 = std::chrono::steady_clock::now();
     CHECK(tz_selfplay_run(sp, directory.c_str(), moves, 32000, "", reload_model, &reload, wait_limit));
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -109,5 +154,6 @@ int main(int argc, char** argv) {
     tz_selfplay_destroy(sp);
     tz_search_destroy(mcts);
     tz_net_destroy(net);
+    if (comm) tz_comm_destroy(comm);
     return 0;
 }

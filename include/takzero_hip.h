@@ -34,8 +34,10 @@ extern "C" {
 
 #define TZ_MAX_N 6
 #define TZ_MAX_SQUARES 36
-/* upper bound on legal moves in one position, per board size 3..6 (used to size rows) */
+/* upper bound on legal moves in one position for board sizes 3..5 (rows of 512); a 6x6 handle uses 1024: ask
+ * tz_search_shape for the row width of a given handle */
 #define TZ_MAX_ACTIONS 512
+#define TZ_MAX_ACTIONS_6 1024
 
 /* error codes */
 #define TZ_OK 0
@@ -122,14 +124,34 @@ int tz_policy_size(int n);
 /* number of input planes: input_channels::<N>(), repr.rs:137-142 */
 int tz_input_channels(int n);
 
-/* ---------- Network lifecycle: Network::{new, load}  (network/mod.rs:10-35) ---------- */
+/* ---------- Network lifecycle: Network::{new, save, load, load_partial, clone}  (network/mod.rs:10-45) ---------- */
 /* blocks = number of residual blocks for TZ_ARCH_TEST (ignored otherwise). */
 int tz_net_create(int board_n, int arch, int device_id, int precision, int blocks, tz_net** out);
-/* Flat weight container written by takzero_amd.weights (named fp32 tensors, state-dict
- * names of the tch VarStore).  A failed load leaves the previous weights active
- * (selfplay/src/main.rs:112-115). */
+/* Network::new(device, seed) (network/mod.rs:11; net5.rs:152-170): tch's default initialisers, draws from a generator
+ * keyed by (seed, variable name); the net is usable afterwards. */
+int tz_net_init_random(tz_net* net, uint64_t seed);
+/* Network::load (network/mod.rs:24-28; net6_simhash.rs:173-190).  The file is recognised by its content: a LibTorch
+ * archive as tch's VarStore::save writes it (`model_latest.ot`, `model_NNNNNNN.ot`: read natively, no LibTorch needed) or
+ * the flat .tzw container of takzero_amd.weights (named fp32 tensors).  SimHash nets also pick up `bitvec.bin` from the
+ * same directory when it is there.  A failed load leaves the previous weights active (selfplay/src/main.rs:112-115). */
 int tz_net_load_weights(tz_net* net, const char* path);
 int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes);
+/* Network::load_partial (network/mod.rs:30-35): variables the file does not hold (or holds with another size) keep their
+ * values; their names come back newline-separated in missing_out (may be NULL), their number in n_missing_out. */
+int tz_net_load_partial(tz_net* net, const char* path, char* missing_out, int missing_cap, int* n_missing_out);
+/* Network::save (network/mod.rs:16-18; net6_simhash.rs:152-170): `*.tzw` = the flat container, anything else = a LibTorch
+ * archive with tch's variable names, written to `<path>.part` and renamed; SimHash nets write `bitvec.bin` beside it. */
+int tz_net_save(tz_net* net, const char* path);
+/* Network::clone(device) (network/mod.rs:37-44): the same variables (and SimHash set) on another GPU. */
+int tz_net_clone(tz_net* net, int device_id, tz_net** out);
+/* One variable of the host-side VarStore by name (`.a.` / `.b.` for the two SmallBlocks of a block); out may be NULL to
+ * ask for the element count only. */
+int tz_net_get_tensor(tz_net* net, const char* name, float* out, uint64_t count, uint64_t* count_out);
+/* enumeration of that store, in name order (as tz_trainer_tensor_count / _info) */
+int tz_net_tensor_count(tz_net* net);
+int tz_net_tensor_info(tz_net* net, int i, char* name_out, int name_cap, uint64_t* count_out);
+/* Converts a model file between the two containers (by content on the way in, by extension on the way out). */
+int tz_weights_convert(const char* src, const char* dst);
 int tz_net_destroy(tz_net* net);
 
 /*
@@ -255,6 +277,39 @@ int tz_selfplay_take_text(tz_selfplay* sp, int which, char* out, uint64_t cap, u
 int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_buffer_len, const char* suffix,
                     int (*reload)(void*), void* reload_user, double wait_limit_s);
 
+/* ---------- N shards: the exchange between the self-play processes of one job, csrc/tz_comm.cpp ----------
+ * The reference runs N selfplay processes that append to the same files of one directory (README.md:130) and has no
+ * collective.  With one process per GPU the shards hand over through a communicator: an all-gather of counts followed by
+ * an all-gather of the packed target records / replay lines after every move, and a broadcast of a new model's weights.
+ * Transports: RCCL (ncclAllGather / ncclBroadcast on the shard's GPU, xGMI inside a node; librccl is opened with dlopen on
+ * first use) and "fs" (files in a shared directory, the reference's own medium: no GPU needed). */
+typedef struct tz_comm tz_comm;
+#define TZ_COMM_ID_BYTES 128
+/* ncclGetUniqueId on one rank; the host carries the 128 bytes to the others (MPI, a TCP store, or the helper below) */
+int tz_comm_unique_id(unsigned char* id_out /*[TZ_COMM_ID_BYTES]*/);
+/* the same through `<directory>/rccl_id.bin`: rank 0 creates and publishes the id, the others wait for it */
+int tz_comm_rendezvous_id(const char* directory, int rank, unsigned char* id_inout, double timeout_s);
+/* ncclCommInitRank for this shard (collective over the world); device_id = the shard's GPU */
+int tz_comm_create_rccl(const unsigned char* id, int rank, int world, int device_id, tz_comm** out);
+int tz_comm_create_fs(const char* directory, int rank, int world, double timeout_s, tz_comm** out);
+int tz_comm_destroy(tz_comm* c);
+int tz_comm_info(tz_comm* c, int* rank_out, int* world_out, int* is_rccl_out, uint64_t* collectives_out, uint64_t* bytes_gathered_out);
+/* variable-size all-gather of host bytes (counts, then padded payloads): sizes_out[world]; the payloads, back to back in
+ * rank order (total_out bytes), stay with the handle until tz_comm_take copies them out */
+int tz_comm_all_gather(tz_comm* c, const void* data, uint64_t bytes, uint64_t* sizes_out, uint64_t* total_out);
+int tz_comm_take(tz_comm* c, void* out, uint64_t out_cap);
+int tz_comm_broadcast(tz_comm* c, void* data, uint64_t bytes, int root);
+int tz_comm_barrier(tz_comm* c);
+/* Net::load for N shards (selfplay/src/main.rs:107-121): the root passes the result of its own load as `status` (0 = a new
+ * model is active on it); every rank then takes the same branch: 0 = receive and activate those variables, else keep. */
+int tz_net_broadcast(tz_net* net, tz_comm* c, int root, int status);
+/* Self-play over N shards: with a communicator set, the targets a move finishes stay packed until tz_selfplay_exchange
+ * (collective, once per tz_selfplay_play_move; tz_selfplay_run calls it) has gathered every rank's; afterwards rank
+ * `writer_rank` (every rank if < 0) holds everybody's target / replay / exploration lines in rank order — for
+ * tz_selfplay_take_text, or appended to the directory's files by tz_selfplay_run — and the other ranks hold none. */
+int tz_selfplay_set_comm(tz_selfplay* sp, tz_comm* c, int writer_rank);
+int tz_selfplay_exchange(tz_selfplay* sp);
+
 /* ---------- reanalyze::main above the search (reanalyze/src/main.rs:60-290), native host code ----------
  * Position buffer fed from replays.txt (complete lines appended since the last call; line i belongs to rank i % world;
  * every pre-move state of a replay, moves re-validated on the device), B positions sampled without replacement,
@@ -315,6 +370,13 @@ int tz_trainer_outputs(tz_trainer* t, float* policy_out, float* value_out, float
 
 /* board size, batch and architecture of a trainer */
 int tz_trainer_shape(tz_trainer* t, int* board_n_out, int* batch_out, int* arch_out);
+/* Network::load / Network::save on the trainer's VarStore (learn/src/main.rs:107-120, 247-266): a LibTorch archive as tch
+ * writes it or the .tzw container; variables the step never touches (RND nets, SimHash matrix) are carried through. */
+int tz_trainer_load(tz_trainer* t, const char* path);
+int tz_trainer_save(tz_trainer* t, const char* path);
+/* the variables of a network (tz_net_init_random = Net::new, or a loaded model) become the trainer's, and back */
+int tz_trainer_from_net(tz_trainer* t, tz_net* net);
+int tz_trainer_to_net(tz_trainer* t, tz_net* net);
 
 /* ---------- learn::main above the step (learn/src/main.rs:99-319, 486-516), native host code (csrc/tz_host_learn.cpp) ----------
  * The two target buffers with forced-use counts (SELFPLAY / REANALYZE_TARGET_FORCED_USES, :59-60) fed by tailing the
@@ -335,6 +397,11 @@ int tz_learn_last_batch(tz_learn* l, tz_state* states_out, float* policy_out, ui
 int tz_learn_run(tz_learn* l, const char* directory, int64_t starting_steps, int64_t steps, int min_selfplay, int min_reanalyze,
                  int64_t steps_before_reanalyze, double read_interval_s, double sleep_s, double wait_limit_s,
                  int (*on_step)(void*, int64_t, const float*, const tz_state*, int), void* user, int64_t* model_steps_out);
+/* The save points of learn::main inside tz_learn_run (learn/src/main.rs:247-266): `model_latest.ot` every steps_per_save
+ * steps (100 in the reference), `model_<steps>.ot` every steps_per_checkpoint (50 000), as LibTorch archives written behind
+ * the training loop; hash_net (may be NULL): a SimHash net whose set is updated with every batch (:418) and saved as
+ * `bitvec.bin` beside the model.  0 = no such save point. */
+int tz_learn_set_save_points(tz_learn* l, int steps_per_save, int steps_per_checkpoint, tz_net* hash_net);
 
 /* Diagnostic: evaluates on the device the f32 primitives the tree kernels must compute exactly as
  * the host does (op 0 exp, 1 ln, 2 sqrt, 3 a/b, 4 0.997^int(a), 5 (a+b)*a). */

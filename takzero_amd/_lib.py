@@ -36,6 +36,10 @@ SYMBOLS = [
     "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
     "tz_selfplay_run", "tz_reanalyze_create", "tz_reanalyze_destroy", "tz_reanalyze_feed", "tz_reanalyze_iterate",
     "tz_reanalyze_take_text", "tz_reanalyze_run", "tz_compete", "tz_puzzle_benchmark", "tz_search_pool_overflows", "tz_trainer_shape",
+    "tz_net_init_random", "tz_net_load_partial", "tz_net_save", "tz_net_clone", "tz_net_get_tensor", "tz_weights_convert", "tz_net_tensor_count", "tz_net_tensor_info",
+    "tz_comm_unique_id", "tz_comm_rendezvous_id", "tz_comm_create_rccl", "tz_comm_create_fs", "tz_comm_destroy", "tz_comm_info",
+    "tz_comm_all_gather", "tz_comm_take", "tz_comm_broadcast", "tz_comm_barrier", "tz_net_broadcast", "tz_selfplay_set_comm", "tz_selfplay_exchange",
+    "tz_trainer_load", "tz_trainer_save", "tz_trainer_from_net", "tz_trainer_to_net", "tz_learn_set_save_points",
     "tz_learn_create", "tz_learn_destroy", "tz_learn_feed", "tz_learn_add_lines", "tz_learn_buffer_len", "tz_learn_step", "tz_learn_run", "tz_learn_last_batch",
 ]
 
@@ -72,6 +76,32 @@ def load():
     lib.tz_net_load_weights.argtypes = [vp, C.c_char_p]
     lib.tz_net_load_weights_mem.argtypes = [vp, vp, C.c_size_t]
     lib.tz_net_destroy.argtypes = [vp]
+    lib.tz_net_init_random.argtypes = [vp, C.c_uint64]
+    lib.tz_net_load_partial.argtypes = [vp, C.c_char_p, C.c_char_p, ci, C.POINTER(ci)]
+    lib.tz_net_save.argtypes = [vp, C.c_char_p]
+    lib.tz_net_clone.argtypes = [vp, ci, C.POINTER(vp)]
+    lib.tz_net_get_tensor.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.tz_weights_convert.argtypes = [C.c_char_p, C.c_char_p]
+    lib.tz_net_tensor_count.argtypes = [vp]
+    lib.tz_comm_unique_id.argtypes = [vp]
+    lib.tz_comm_rendezvous_id.argtypes = [C.c_char_p, ci, vp, C.c_double]
+    lib.tz_comm_create_rccl.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
+    lib.tz_comm_create_fs.argtypes = [C.c_char_p, ci, ci, C.c_double, C.POINTER(vp)]
+    lib.tz_comm_destroy.argtypes = [vp]
+    lib.tz_comm_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.tz_comm_all_gather.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
+    lib.tz_comm_take.argtypes = [vp, vp, C.c_uint64]
+    lib.tz_comm_broadcast.argtypes = [vp, vp, C.c_uint64, ci]
+    lib.tz_comm_barrier.argtypes = [vp]
+    lib.tz_net_broadcast.argtypes = [vp, vp, ci, ci]
+    lib.tz_selfplay_set_comm.argtypes = [vp, vp, ci]
+    lib.tz_selfplay_exchange.argtypes = [vp]
+    lib.tz_trainer_load.argtypes = [vp, C.c_char_p]
+    lib.tz_trainer_save.argtypes = [vp, C.c_char_p]
+    lib.tz_trainer_from_net.argtypes = [vp, vp]
+    lib.tz_trainer_to_net.argtypes = [vp, vp]
+    lib.tz_learn_set_save_points.argtypes = [vp, ci, ci, vp]
+    lib.tz_net_tensor_info.argtypes = [vp, ci, C.c_char_p, ci, C.POINTER(C.c_uint64)]
     lib.tz_net_eval.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp]
     lib.tz_net_encode.argtypes = [vp, ci, vp, vp]
     lib.tz_net_forward_raw.argtypes = [vp, ci, vp, vp, vp, vp]

@@ -112,21 +112,10 @@ class Net:
             pass
 
     def load(self, path):
-        """Network::load (network/mod.rs:24-28).  `.ot` = the reference's LibTorch archive (converted on the host,
-        takzero_amd.ot); anything else = the flat .tzw container.  SimHash nets also pick up `bitvec.bin` from the
-        same directory (net6_simhash.rs:173-190)."""
-        path = str(path)
-        if path.endswith(".ot"):
-            import os
-
-            from . import ot
-
-            self.load_tensors(ot.load_ot(path))
-            bits = os.path.join(os.path.dirname(path), "bitvec.bin")
-            if self.arch in (ARCH_NET4_SIMHASH, ARCH_NET6_SIMHASH) and os.path.exists(bits):
-                self.load_bitset(bits)
-            return self
-        check(self.lib.tz_net_load_weights(self.h, path.encode()))
+        """Network::load (network/mod.rs:24-28; net6_simhash.rs:173-190): a LibTorch archive as the reference's `learn`
+        writes it (`.ot`, read natively by the library) or the flat .tzw container, recognised by content; SimHash nets also
+        pick up `bitvec.bin` from the same directory."""
+        check(self.lib.tz_net_load_weights(self.h, str(path).encode()))
         return self
 
     def load_tensors(self, tensors):
@@ -135,60 +124,46 @@ class Net:
         blob = dumps_tzw(tensors)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         check(self.lib.tz_net_load_weights_mem(self.h, C.addressof(buf), len(blob)))
-        self._tensors = tensors   # the VarStore's host copy, for save / clone (not copied: callers hand over ownership)
         return self
 
     @classmethod
     def new(cls, arch=ARCH_NET5, seed=None, n=0, device=0, precision=None, blocks=0):
-        """Network::new(device, seed) (network/mod.rs:11): randomly initialised weights, tch's default initialisers."""
-        from . import weights as W
-
+        """Network::new(device, seed) (network/mod.rs:11): randomly initialised weights, tch's default initialisers
+        (tz_net_init_random)."""
         net = cls(arch=arch, n=n, device=device, precision=precision, blocks=blocks)
-        net.device, net.blocks = device, blocks
-        return net.load_tensors(W.init_weights(arch, n=n, blocks=blocks, seed=0 if seed is None else seed))
+        check(net.lib.tz_net_init_random(net.h, 0 if seed is None else int(seed)))
+        return net
+
+    def tensors(self):
+        """The host-side VarStore: name -> fp32 array (flat), as loaded / initialised."""
+        out, buf, cnt = {}, C.create_string_buffer(256), C.c_uint64()
+        for i in range(self.lib.tz_net_tensor_count(self.h)):
+            check(self.lib.tz_net_tensor_info(self.h, i, buf, 256, C.byref(cnt)))
+            arr = np.zeros(cnt.value, np.float32)
+            check(self.lib.tz_net_get_tensor(self.h, buf.value, arr.ctypes.data, arr.size, None))
+            out[buf.value.decode()] = arr
+        return out
 
     def save(self, path):
-        """Network::save (network/mod.rs:16-18): `.ot` = LibTorch archive as tch writes it, else the .tzw container."""
-        tensors = getattr(self, "_tensors", None)
-        if tensors is None:
-            raise TakzeroError(-6, "save: the network has no weights loaded through this object")
-        if str(path).endswith(".ot"):
-            from . import ot
-
-            ot.save_ot(path, tensors)
-        else:
-            from .weights import save_tzw
-
-            save_tzw(path, tensors)
+        """Network::save (network/mod.rs:16-18; net6_simhash.rs:152-170): `*.tzw` = the flat container, else a LibTorch
+        archive as tch writes it (+ `bitvec.bin` beside it for SimHash nets)."""
+        check(self.lib.tz_net_save(self.h, str(path).encode()))
 
     def load_partial(self, path):
         """Network::load_partial (network/mod.rs:30-35): variables missing from the file keep their current values;
         returns their names (tch's VarStore::load_partial)."""
-        from . import ot
-        from .weights import load_tzw
-
-        have = getattr(self, "_tensors", None)
-        if have is None:
-            raise TakzeroError(-6, "load_partial: initialise the network first (Net.new or load)")
-        found = ot.load_ot(path) if str(path).endswith(".ot") else load_tzw(path)
-        merged = dict(have)
-        missing = [k for k in have if k not in found]
-        for k, v in found.items():
-            if k in merged and np.shape(v) == np.shape(merged[k]):
-                merged[k] = v
-            elif k in merged:
-                missing.append(k)
-        self.load_tensors(merged)
-        return missing
+        buf, n = C.create_string_buffer(1 << 16), C.c_int()
+        check(self.lib.tz_net_load_partial(self.h, str(path).encode(), buf, len(buf), C.byref(n)))
+        return [x for x in buf.value.decode().split("\n") if x]
 
     def clone(self, device=0):
         """Network::clone(device) (network/mod.rs:37-44): the same weights on another GPU."""
-        tensors = getattr(self, "_tensors", None)
-        if tensors is None:
-            raise TakzeroError(-6, "clone: the network has no weights loaded through this object")
-        other = Net(arch=self.arch, n=self.n, device=device, precision=self.precision, blocks=getattr(self, "blocks", 0))
-        other.blocks = getattr(self, "blocks", 0)
-        return other.load_tensors(tensors)
+        h = C.c_void_p()
+        check(self.lib.tz_net_clone(self.h, device, C.byref(h)))
+        other = Net.__new__(Net)
+        other.lib, other.h = self.lib, h
+        other.arch, other.precision, other.blocks, other.device, other.n = self.arch, self.precision, self.blocks, device, self.n
+        return other
 
     def policy_value_uncertainty(self, env_batch, actions_batch):
         """Agent::policy_value_uncertainty: returns (list of per-env logits arrays, values, variances)."""

@@ -11,8 +11,10 @@ ARCH = "gfx950"
 # no FMA contraction there.  The network kernels keep the default (contraction on).
 UNITS = [
     ("tz_text.cpp", ["-ffp-contract=off"]),
+    ("tz_ot.cpp", []),
     ("tz_host.cpp", ["-ffp-contract=off"]),
     ("tz_host_learn.cpp", ["-ffp-contract=off"]),
+    ("tz_comm.cpp", []),
     ("tz_tree.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_capi.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_nn.hip", []),
@@ -55,7 +57,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed")
     if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", OUT] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", OUT] + objs + ["-ldl"]
         subprocess.check_call(cmd)
     return OUT
 

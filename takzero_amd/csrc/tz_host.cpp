@@ -6,6 +6,9 @@
 //
 // Randomness (openings, Dirichlet / Gumbel samples, early-ply move sampling) is drawn here from one seeded
 // std::mt19937_64 per shard and handed to the search as input, exactly as the Python driver does with numpy.
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -20,6 +23,7 @@
 #include <vector>
 
 #include "tz_engine.h"
+#include "tz_host_exchange.h"
 #include "tz_math.h"
 
 // Every call into the search goes through these two names, so that a test build can bind this same driver to another
@@ -30,6 +34,24 @@
 #endif
 
 namespace {
+
+// OpenOptions::append(true).create(true) + ONE write of the whole text (selfplay/src/main.rs:332-366): several processes
+// append to the same file - one per GPU here, 10 selfplay + 10 reanalyze processes in the reference's deployment
+// (README.md:130) - and a reader must never find two writers' bytes interleaved inside a line.  stdio would split the text
+// into buffer-sized writes.
+bool append_whole(const std::string& path, const std::string& text) {
+    if (text.empty()) return true;
+    const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
+    if (fd < 0) return false;
+    size_t done = 0;
+    while (done < text.size()) {   // a regular file takes it in one call; the loop is for the contract of write()
+        const ssize_t w = write(fd, text.data() + done, text.size() - done);
+        if (w <= 0) break;
+        done += (size_t)w;
+    }
+    close(fd);
+    return done == text.size();
+}
 
 constexpr float NOISE_ALPHA = 0.05f;          // selfplay/src/main.rs:39
 constexpr float NOISE_RATIO = 0.2f;           // selfplay/src/main.rs:40
@@ -99,9 +121,63 @@ struct tz_selfplay {
     std::vector<uint16_t> t_moves;
     std::vector<float> t_pol, t_value, t_ube;
     std::vector<int32_t> t_n;
+    // N shards (tz_selfplay_set_comm): the targets a move finished stay packed until tz_selfplay_exchange has gathered
+    // every rank's; records = [u32 n][f32 value][f32 ube][tz_state][u16 move x n, padded to 4][f32 p x n]
+    bool has_exchange = false;
+    HostExchange xch;
+    std::vector<unsigned char> records;
+    uint64_t n_gathered = 0;
 };
 
 namespace {
+
+// packed target records of the exchange (tz_selfplay struct): append / parse
+void pack_records(int n, int T, int amax, const std::vector<tz_state>& st, const std::vector<uint16_t>& moves, const std::vector<float>& pol,
+                  const std::vector<int32_t>& cnt, const std::vector<float>& value, const std::vector<float>& ube,
+                  std::vector<unsigned char>& out) {
+    (void)n;
+    for (int i = 0; i < T; i++) {
+        const uint32_t c = (uint32_t)cnt[i];
+        const size_t mv_bytes = ((size_t)c * 2 + 3) / 4 * 4;
+        const size_t at = out.size();
+        out.resize(at + 12 + sizeof(tz_state) + mv_bytes + (size_t)c * 4, 0);
+        unsigned char* p = out.data() + at;
+        memcpy(p, &c, 4);
+        memcpy(p + 4, &value[i], 4);
+        memcpy(p + 8, &ube[i], 4);
+        memcpy(p + 12, &st[i], sizeof(tz_state));
+        memcpy(p + 12 + sizeof(tz_state), moves.data() + (size_t)i * amax, (size_t)c * 2);
+        memcpy(p + 12 + sizeof(tz_state) + mv_bytes, pol.data() + (size_t)i * amax, (size_t)c * 4);
+    }
+}
+
+int unpack_records(const std::vector<unsigned char>& in, int amax, std::vector<tz_state>& st, std::vector<uint16_t>& moves,
+                   std::vector<float>& pol, std::vector<int32_t>& cnt, std::vector<float>& value, std::vector<float>& ube) {
+    size_t at = 0;
+    while (at < in.size()) {
+        if (at + 12 + sizeof(tz_state) > in.size()) return tz_fail(TZ_EPARSE, "exchange: truncated target record");
+        uint32_t c;
+        float v, u;
+        memcpy(&c, in.data() + at, 4);
+        memcpy(&v, in.data() + at + 4, 4);
+        memcpy(&u, in.data() + at + 8, 4);
+        const size_t mv_bytes = ((size_t)c * 2 + 3) / 4 * 4;
+        if ((int)c > amax || at + 12 + sizeof(tz_state) + mv_bytes + (size_t)c * 4 > in.size()) return tz_fail(TZ_EPARSE, "exchange: bad target record");
+        tz_state s;
+        memcpy(&s, in.data() + at + 12, sizeof s);
+        st.push_back(s);
+        cnt.push_back((int32_t)c);
+        value.push_back(v);
+        ube.push_back(u);
+        const size_t row = moves.size();
+        moves.resize(row + amax, 0);
+        pol.resize(row + amax, 0.f);
+        memcpy(moves.data() + row, in.data() + at + 12 + sizeof s, (size_t)c * 2);
+        memcpy(pol.data() + row, in.data() + at + 12 + sizeof s + mv_bytes, (size_t)c * 4);
+        at += 12 + sizeof s + mv_bytes + (size_t)c * 4;
+    }
+    return TZ_OK;
+}
 
 int fetch_children(tz_selfplay* sp, int* width_out) {
     int rc = TZS(root_info)(sp->search, sp->info.data());
@@ -324,7 +400,10 @@ int complete(tz_selfplay* sp) {  // restart_envs_and_complete_targets (selfplay/
             sp->start_states[g] = fresh[g];
         }
         const int T = (int)sp->t_n.size();
-        if (T > 0) {
+        if (T > 0 && sp->has_exchange) {
+            pack_records(sp->n, T, amax, sp->t_states, sp->t_moves, sp->t_pol, sp->t_n, sp->t_value, sp->t_ube, sp->records);
+            sp->n_targets += (uint64_t)T;
+        } else if (T > 0) {
             uint64_t total_moves = 0;
             for (int v : sp->t_n) total_moves += (uint64_t)v;
             std::vector<char> out((size_t)T * 200 + total_moves * 40);
@@ -475,6 +554,54 @@ int tz_selfplay_take_text(tz_selfplay* sp, int which, char* out, uint64_t cap, u
 // buffer_lengths.txt says learn has more than `max_buffer_len` self-play targets (:90-105, 371-387), call `reload`
 // (Net::load of model_latest, :107-121; may be null), play a move, append targets-selfplay<suffix>.txt /
 // replays<suffix>.txt / replays-exploration<suffix>.txt from a writer thread.  wait_limit_s < 0: wait forever.
+int tz_selfplay_set_exchange(tz_selfplay* sp, const HostExchange* x) {
+    if (!sp) return tz_fail(TZ_EINVAL, "tz_selfplay_set_exchange: null handle");
+    sp->has_exchange = x != nullptr && x->world > 1;
+    if (x) sp->xch = *x;
+    return TZ_OK;
+}
+
+// The hand-over of one move between the shards (collective: every rank calls it once per tz_selfplay_play_move): all-gather
+// of the packed targets, of the replay lines and of the exploration lines; afterwards the writer rank (every rank when
+// writer < 0) holds everybody's as text, in rank order, for tz_selfplay_take_text / the run loop; the other ranks hold none.
+int tz_selfplay_exchange(tz_selfplay* sp) {
+    if (!sp) return tz_fail(TZ_EINVAL, "tz_selfplay_exchange: null handle");
+    if (!sp->has_exchange) return TZ_OK;
+    const bool keep = sp->xch.writer < 0 || sp->xch.writer == sp->xch.rank;
+    std::vector<std::vector<unsigned char>> all;
+    int rc = sp->xch.all_gather(sp->records, all);
+    sp->records.clear();
+    if (rc) return rc;
+    if (keep) {
+        std::vector<tz_state> st;
+        std::vector<uint16_t> moves;
+        std::vector<float> pol, value, ube;
+        std::vector<int32_t> cnt;
+        for (auto& blob : all)
+            if ((rc = unpack_records(blob, sp->amax, st, moves, pol, cnt, value, ube))) return rc;
+        const int T = (int)cnt.size();
+        if (T > 0) {
+            uint64_t total_moves = 0;
+            for (int v : cnt) total_moves += (uint64_t)v;
+            std::vector<char> out((size_t)T * 200 + total_moves * 40);
+            uint64_t written = 0;
+            if ((rc = tz_format_targets(sp->n, T, st.data(), moves.data(), pol.data(), cnt.data(), sp->amax, value.data(), ube.data(), out.data(),
+                                        out.size(), &written)))
+                return rc;
+            sp->targets_text.append(out.data(), written);
+            sp->n_gathered += (uint64_t)T;
+        }
+    }
+    for (std::string* text : {&sp->replays_text, &sp->exploration_text}) {
+        std::vector<unsigned char> mine(text->begin(), text->end());
+        if ((rc = sp->xch.all_gather(mine, all))) return rc;
+        text->clear();
+        if (keep)
+            for (auto& blob : all) text->append(blob.begin(), blob.end());
+    }
+    return TZ_OK;
+}
+
 int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_buffer_len, const char* suffix,
                     int (*reload)(void*), void* reload_user, double wait_limit_s) {
     if (!sp || !directory) return tz_fail(TZ_EINVAL, "tz_selfplay_run: bad argument");
@@ -488,10 +615,7 @@ int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_b
     bool done = false;
     std::string write_error;
     auto append = [&](const std::string& name, const std::string& text) {
-        if (text.empty()) return;
-        FILE* f = fopen((dir + "/" + name + suf + ".txt").c_str(), "ab");  // OpenOptions::append(true).create(true)
-        if (!f || fwrite(text.data(), 1, text.size(), f) != text.size()) write_error = "cannot append to " + name;
-        if (f) fclose(f);
+        if (!append_whole(dir + "/" + name + suf + ".txt", text)) write_error = "cannot append to " + name;
     };
     std::thread writer([&] {
         for (;;) {
@@ -534,6 +658,12 @@ int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_b
         }
         if (reload && (rc = reload(reload_user))) break;
         if ((rc = tz_selfplay_play_move(sp))) break;
+        if ((rc = tz_selfplay_exchange(sp))) break;   // N shards: the writer rank appends everybody's lines
+        if (sp->has_exchange && sp->xch.writer < 0 && sp->xch.rank != 0) {   // every rank holds them: one copy goes to the files
+            sp->targets_text.clear();
+            sp->replays_text.clear();
+            sp->exploration_text.clear();
+        }
         Job job;
         job.targets.swap(sp->targets_text);
         job.replays.swap(sp->replays_text);
@@ -855,12 +985,8 @@ int tz_reanalyze_run(tz_reanalyze* ra, const char* directory, int iterations, in
             continue;
         }
         if ((rc = tz_reanalyze_iterate(ra))) return rc;
-        FILE* out = fopen((dir + "/targets-reanalyze" + suf + ".txt").c_str(), "ab");
-        if (!out || fwrite(ra->targets_text.data(), 1, ra->targets_text.size(), out) != ra->targets_text.size()) {
-            if (out) fclose(out);
+        if (!append_whole(dir + "/targets-reanalyze" + suf + ".txt", ra->targets_text))
             return tz_fail(TZ_ESTATE, "tz_reanalyze_run: cannot append targets-reanalyze");
-        }
-        fclose(out);
         ra->targets_text.clear();
         it++;
     }

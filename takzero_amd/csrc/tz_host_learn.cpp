@@ -16,6 +16,9 @@
 #include <vector>
 
 #include "tz_engine.h"
+#include "tz_ot.h"
+
+extern "C" int tz_trainer_snapshot(tz_trainer* t, TensorStore& out);   // tz_learn.hip
 
 namespace {
 
@@ -61,6 +64,11 @@ struct tz_learn {
         std::vector<uint8_t> mask;
     } tensors[2];
     uint64_t steps_done = 0;
+    // save points of learn::main (learn/src/main.rs:247-266), written by tz_learn_run itself when set (tz_learn_set_save_points)
+    int steps_per_save = 0, steps_per_checkpoint = 0;
+    tz_net* hash_net = nullptr;           // SimHash nets: update_counts after every step (:418), bitvec.bin beside the model
+    std::thread writer;                   // the archive of the previous save point, written behind the training loop
+    std::string writer_error;
 };
 
 namespace {
@@ -220,6 +228,7 @@ int tz_learn_create(tz_trainer* trainer, int half_komi, uint64_t seed, int selfp
 }
 
 int tz_learn_destroy(tz_learn* l) {
+    if (l && l->writer.joinable()) l->writer.join();
     delete l;
     return TZ_OK;
 }
@@ -301,11 +310,37 @@ int tz_learn_run(tz_learn* l, const char* directory, int64_t starting_steps, int
     std::string pending_error;   // the error text is per thread: carry it over from the worker
     int64_t pending_step = 0;
     int slot = 0, pending_slot = 0, rc = TZ_OK;
+    // a save point: the weights are read back here (the step has finished), the archive is written by a thread while
+    // training goes on; at most one archive is in flight
+    auto save_point = [&](int64_t step_no) -> int {
+        const bool latest = l->steps_per_save > 0 && step_no % l->steps_per_save == 0;
+        const bool numbered = l->steps_per_checkpoint > 0 && step_no % l->steps_per_checkpoint == 0;
+        if (!latest && !numbered) return TZ_OK;
+        if (l->writer.joinable()) l->writer.join();
+        if (!l->writer_error.empty()) return tz_fail(TZ_EINVAL, "tz_learn_run: writing a model file failed: " + l->writer_error);
+        auto snap = std::make_shared<TensorStore>();
+        int r = tz_trainer_snapshot(l->trainer, *snap);
+        if (r) return r;
+        if (l->hash_net && (r = tz_net_save_bitset(l->hash_net, (dir + "/bitvec.bin").c_str()))) return r;   // net6_simhash.rs:152-170
+        char numbered_name[64];
+        snprintf(numbered_name, sizeof numbered_name, "/model_%07lld.ot", (long long)step_no);
+        const std::string a = latest ? dir + "/model_latest.ot" : std::string(), b = numbered ? dir + numbered_name : std::string();
+        l->writer = std::thread([l, snap, a, b]() {
+            if (!a.empty() && weights_write_file(a.c_str(), *snap)) l->writer_error = tz_last_error();
+            if (!b.empty() && weights_write_file(b.c_str(), *snap)) l->writer_error = tz_last_error();
+        });
+        return TZ_OK;
+    };
     auto finish = [&]() -> int {
         if (!pending.valid()) return TZ_OK;
         int r = pending.get();
         if (r) return tz_fail(r, pending_error);
         l->steps_done++;
+        if (l->hash_net) {   // net.update_counts(&tensors.input), learn/src/main.rs:418
+            std::vector<uint32_t> idx(l->B);
+            if ((r = tz_net_hash_indices(l->hash_net, l->B, l->tensors[pending_slot].states.data(), idx.data(), 1))) return r;
+        }
+        if ((r = save_point(pending_step))) return r;
         if (on_step && on_step(user, pending_step, pending_losses, l->tensors[pending_slot].states.data(), l->B))
             return tz_fail(TZ_ESTATE, "tz_learn_run: the on_step callback asked to stop");
         return TZ_OK;
@@ -350,8 +385,18 @@ int tz_learn_run(tz_learn* l, const char* directory, int64_t starting_steps, int
     }
     const int last = finish();
     if (!rc) rc = last;
+    if (l->writer.joinable()) l->writer.join();
+    if (!rc && !l->writer_error.empty()) rc = tz_fail(TZ_EINVAL, "tz_learn_run: writing a model file failed: " + l->writer_error);
     if (model_steps_out) *model_steps_out = rc ? model_steps - 1 : model_steps;
     return rc;
+}
+
+int tz_learn_set_save_points(tz_learn* l, int steps_per_save, int steps_per_checkpoint, tz_net* hash_net) {
+    if (!l || steps_per_save < 0 || steps_per_checkpoint < 0) return tz_fail(TZ_EINVAL, "tz_learn_set_save_points: bad argument");
+    l->steps_per_save = steps_per_save;
+    l->steps_per_checkpoint = steps_per_checkpoint;
+    l->hash_net = hash_net;
+    return TZ_OK;
 }
 
 }  // extern "C"

@@ -542,6 +542,7 @@ struct tz_trainer {
     hipEvent_t ev_dc[2] = {nullptr, nullptr}, ev_w[2] = {nullptr, nullptr};
     float* dC2 = nullptr;
     std::vector<void*> allocs;
+    TensorStore extra;   // variables of the VarStore the step never touches (RND nets, SimHash matrix): carried through save / load
 };
 
 namespace {
@@ -962,6 +963,79 @@ int tz_trainer_get_tensor(tz_trainer* t, const char* name, int what, float* out,
         memcpy(out, host.data(), count * sizeof(float));
     }
     return TZ_OK;
+}
+
+// shape of a variable in the reference's VarStore
+static std::vector<uint32_t> param_dims(const tz_trainer* t, const Param& p) {
+    auto ends = [&](const char* s) { const size_t n = strlen(s); return p.name.size() >= n && !p.name.compare(p.name.size() - n, n, s); };
+    if (p.kind == 1) return {(uint32_t)p.co, (uint32_t)p.ci, 3u, 3u};
+    if (ends("value.conv2d.weight") || ends("ube.conv2d.weight")) return {1u, (uint32_t)p.count, 1u, 1u};
+    if (ends(".linear.weight")) return {1u, (uint32_t)t->nn};
+    return {(uint32_t)p.count};
+}
+
+// The trainer's VarStore as a host store (current parameters and buffers + the carried extras)
+int tz_trainer_snapshot(tz_trainer* t, TensorStore& out) {
+    out = t->extra;
+    for (const Param& p : t->params) {
+        HostTensor h;
+        h.dims = param_dims(t, p);
+        h.data.resize(p.count);
+        int rc = tz_trainer_get_tensor(t, p.name.c_str(), 0, h.data.data(), p.count);
+        if (rc) return rc;
+        out[p.name] = std::move(h);
+    }
+    return TZ_OK;
+}
+
+static int trainer_apply_store(tz_trainer* t, const TensorStore& st) {
+    for (const Param& p : t->params) {
+        auto it = st.find(p.name);
+        if (it == st.end()) return tz_fail(TZ_EPARSE, "trainer: the model has no variable " + p.name);
+        if (it->second.data.size() != p.count) return tz_fail(TZ_EPARSE, "trainer: wrong size of variable " + p.name);
+    }
+    for (const Param& p : t->params) {
+        int rc = tz_trainer_set_tensor(t, p.name.c_str(), 0, st.at(p.name).data.data(), p.count);
+        if (rc) return rc;
+    }
+    t->extra.clear();
+    for (auto& kv : st)
+        if (!t->index.count(kv.first)) t->extra[kv.first] = kv.second;
+    return TZ_OK;
+}
+
+// Network::load / Network::save on the trainer's VarStore (learn/src/main.rs:107-120, 247-266): LibTorch archive or .tzw
+int tz_trainer_load(tz_trainer* t, const char* path) {
+    if (!t || !path) return tz_fail(TZ_EINVAL, "tz_trainer_load: null argument");
+    TensorStore st;
+    int rc = weights_read_file(path, st);
+    if (rc) return rc;
+    return trainer_apply_store(t, st);
+}
+
+int tz_trainer_save(tz_trainer* t, const char* path) {
+    if (!t || !path) return tz_fail(TZ_EINVAL, "tz_trainer_save: null argument");
+    TensorStore st;
+    int rc = tz_trainer_snapshot(t, st);
+    if (rc) return rc;
+    return weights_write_file(path, st);
+}
+
+// the variables of a network (Net::new / a loaded model) become the trainer's, and back without a file
+int tz_trainer_from_net(tz_trainer* t, tz_net* net) {
+    if (!t || !net) return tz_fail(TZ_EINVAL, "tz_trainer_from_net: null argument");
+    if (!net->loaded) return tz_fail(TZ_ESTATE, "tz_trainer_from_net: the network has no weights");
+    return trainer_apply_store(t, net->store);
+}
+
+int tz_trainer_to_net(tz_trainer* t, tz_net* net) {
+    if (!t || !net) return tz_fail(TZ_EINVAL, "tz_trainer_to_net: null argument");
+    TensorStore st;
+    int rc = tz_trainer_snapshot(t, st);
+    if (rc) return rc;
+    std::vector<unsigned char> blob;
+    tzw_dump(st, blob);
+    return tz_net_load_weights_mem(net, blob.data(), blob.size());
 }
 
 // compute_loss_and_take_step (learn/src/main.rs:376-423) on one batch:

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "tz_engine.h"
+#include "tz_ot.h"
 
 struct ConvW {
     int taps = 0, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
@@ -18,6 +19,7 @@ struct tz_net {
     int n = 0, nn = 0, arch = 0, device = 0, precision = 0, blocks = 0;
     int cin = 0, cin_pad = 0, pol_ch = 0, pol_stride = 0, ppt = 0;
     bool loaded = false, has_rnd = false, has_hash = false;
+    TensorStore store;         // host copy of the VarStore (fp32, `.a.` / `.b.` names): tz_net_save / clone / load_partial
     uint64_t weights_gen = 0;  // bumped by every successful load: captured graphs hold weight pointers
     ConvW conv_in, policy;
     std::vector<ConvW> res;  // 2 per block

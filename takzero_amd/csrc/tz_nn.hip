@@ -15,6 +15,7 @@
 //     (net6_simhash.rs:208-256) with the 2^32-bit set resident in HBM.
 //   * an fp32 validation path (TZ_PREC_F32) with plain FMA kernels for the 1e-3 logit gate.
 #include "tz_nn.h"
+#include "tz_ot.h"
 
 #include <cmath>
 #include <cstdio>
@@ -1989,36 +1990,16 @@ struct Tensor {
 };
 typedef std::map<std::string, Tensor> TensorMap;
 
-int parse_tzw(const unsigned char* p, size_t bytes, TensorMap& out) {
-    if (bytes < 8 || memcmp(p, "TZW1", 4)) return tz_fail(TZ_EPARSE, "weights: bad magic");
-    uint32_t count;
-    memcpy(&count, p + 4, 4);
-    size_t off = 8;
-    for (uint32_t i = 0; i < count; i++) {
-        if (off + 2 > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
-        uint16_t ln;
-        memcpy(&ln, p + off, 2);
-        off += 2;
-        if (off + ln + 1 > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
-        std::string name((const char*)p + off, ln);
-        off += ln;
-        const int nd = p[off++];
+TensorMap view_of(const TensorStore& store) {
+    TensorMap m;
+    for (auto& kv : store) {
         Tensor t;
-        t.size = 1;
-        if (off + 4 * (size_t)nd > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
-        for (int d = 0; d < nd; d++) {
-            uint32_t v;
-            memcpy(&v, p + off, 4);
-            off += 4;
-            t.dims.push_back(v);
-            t.size *= v;
-        }
-        if (off + 4 * t.size > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
-        t.data = reinterpret_cast<const float*>(p + off);  // may be unaligned: copied with memcpy below
-        off += 4 * t.size;
-        out[name] = t;
+        t.dims = kv.second.dims;
+        t.data = kv.second.data.data();
+        t.size = kv.second.data.size();
+        m[kv.first] = t;
     }
-    return TZ_OK;
+    return m;
 }
 
 int get_tensor(const TensorMap& m, const std::string& name, size_t expect, std::vector<float>& out) {
@@ -2855,17 +2836,16 @@ int tz_net_create(int board_n, int arch, int device_id, int precision, int block
     return TZ_OK;
 }
 
-int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
-    if (!net || !data) return tz_fail(TZ_EINVAL, "tz_net_load_weights: null argument");
+// Replaces the network's weights by `store` (all or nothing: a failure leaves the previous weights active,
+// selfplay/src/main.rs:112-115) and keeps the store as the host copy of the VarStore (save / clone / load_partial).
+static int net_apply_store(tz_net* net, TensorStore&& store) {
     TZ_HIP(hipSetDevice(net->device));
-    TensorMap m;
-    int rc = parse_tzw((const unsigned char*)data, bytes, m);
-    if (rc) return rc;
+    const TensorMap m = view_of(store);
     NetWeights W;
-    rc = build_weights(net, m, W);
+    int rc = build_weights(net, m, W);
     if (rc) {
         free_weights(W);
-        return rc;  // old weights stay active (selfplay/src/main.rs:112-115)
+        return rc;
     }
     TZ_HIP(hipDeviceSynchronize());  // searches run this net on their own streams; reloads are rare
     NetWeights old;
@@ -2898,23 +2878,256 @@ int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
     net->rnd_max = W.rnd_max;
     net->simhash = W.simhash;
     free_weights(old);
+    net->store = std::move(store);
     net->loaded = true;
     net->weights_gen++;
     return TZ_OK;
 }
 
+static bool file_exists(const std::string& p) {
+    FILE* f = fopen(p.c_str(), "rb");
+    if (f) fclose(f);
+    return f != nullptr;
+}
+static std::string sibling(const char* path, const char* name) {
+    const std::string p(path);
+    const size_t slash = p.find_last_of('/');
+    return (slash == std::string::npos ? std::string() : p.substr(0, slash + 1)) + name;
+}
+
+int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes) {
+    if (!net || !data) return tz_fail(TZ_EINVAL, "tz_net_load_weights: null argument");
+    TensorStore store;
+    const unsigned char* p = (const unsigned char*)data;
+    int rc;
+    if (bytes >= 4 && !memcmp(p, "PK\x03\x04", 4)) {   // a LibTorch archive held in memory
+        NamedTensors named;
+        if ((rc = ot_read_archive(p, bytes, named))) return rc;
+        if ((rc = ot_canonical_names(named, store))) return rc;
+    } else if ((rc = tzw_parse(p, bytes, store))) {
+        return rc;
+    }
+    return net_apply_store(net, std::move(store));
+}
+
 int tz_net_load_weights(tz_net* net, const char* path) {
     if (!net || !path) return tz_fail(TZ_EINVAL, "tz_net_load_weights: null argument");
-    FILE* f = fopen(path, "rb");
-    if (!f) return tz_fail(TZ_EPARSE, std::string("tz_net_load_weights: cannot open ") + path);
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<unsigned char> buf(sz > 0 ? sz : 0);
-    const size_t rd = sz > 0 ? fread(buf.data(), 1, sz, f) : 0;
-    fclose(f);
-    if ((long)rd != sz) return tz_fail(TZ_EPARSE, "tz_net_load_weights: short read");
-    return tz_net_load_weights_mem(net, buf.data(), buf.size());
+    TensorStore store;
+    int rc = weights_read_file(path, store);
+    if (rc) return rc;
+    if ((rc = net_apply_store(net, std::move(store)))) return rc;
+    // SimHash nets keep their set beside the model (net6_simhash.rs:173-190)
+    if (net->has_hash) {
+        const std::string bits = sibling(path, "bitvec.bin");
+        if (file_exists(bits)) return tz_net_load_bitset(net, bits.c_str());
+    }
+    return TZ_OK;
+}
+
+int tz_net_load_partial(tz_net* net, const char* path, char* missing_out, int missing_cap, int* n_missing_out) {
+    if (!net || !path) return tz_fail(TZ_EINVAL, "tz_net_load_partial: null argument");
+    if (!net->loaded) return tz_fail(TZ_ESTATE, "tz_net_load_partial: initialise the network first (tz_net_init_random or a full load)");
+    TensorStore found, merged = net->store;
+    int rc = weights_read_file(path, found);
+    if (rc) return rc;
+    std::string missing;
+    int n_missing = 0;
+    for (auto& kv : merged) {
+        auto it = found.find(kv.first);
+        if (it != found.end() && it->second.data.size() == kv.second.data.size()) {
+            kv.second = it->second;
+        } else {
+            missing += kv.first + "\n";
+            n_missing++;
+        }
+    }
+    if ((rc = net_apply_store(net, std::move(merged)))) return rc;
+    if (n_missing_out) *n_missing_out = n_missing;
+    if (missing_out && missing_cap > 0) {
+        const size_t k = std::min(missing.size(), (size_t)missing_cap - 1);
+        memcpy(missing_out, missing.data(), k);
+        missing_out[k] = 0;
+    }
+    return TZ_OK;
+}
+
+int tz_net_save(tz_net* net, const char* path) {
+    if (!net || !path) return tz_fail(TZ_EINVAL, "tz_net_save: null argument");
+    if (!net->loaded) return tz_fail(TZ_ESTATE, "tz_net_save: the network has no weights");
+    int rc = weights_write_file(path, net->store);
+    if (rc) return rc;
+    if (net->has_hash) return tz_net_save_bitset(net, sibling(path, "bitvec.bin").c_str());   // net6_simhash.rs:152-170
+    return TZ_OK;
+}
+
+int tz_net_clone(tz_net* net, int device_id, tz_net** out) {
+    if (!net || !out) return tz_fail(TZ_EINVAL, "tz_net_clone: null argument");
+    if (!net->loaded) return tz_fail(TZ_ESTATE, "tz_net_clone: the network has no weights");
+    tz_net* other = nullptr;
+    int rc = tz_net_create(net->arch == TZ_ARCH_TEST ? net->n : 0, net->arch, device_id, net->precision, net->blocks, &other);
+    if (rc) return rc;
+    TensorStore copy = net->store;
+    if ((rc = net_apply_store(other, std::move(copy)))) {
+        tz_net_destroy(other);
+        return rc;
+    }
+    if (net->has_hash) {
+        if (hipMemcpy(other->bitset, net->bitset, (size_t)1 << 29, hipMemcpyDeviceToDevice) != hipSuccess) {
+            tz_net_destroy(other);
+            return tz_fail(TZ_EDEVICE, "tz_net_clone: copying the SimHash set failed");
+        }
+    }
+    *out = other;
+    return TZ_OK;
+}
+
+int tz_net_get_tensor(tz_net* net, const char* name, float* out, uint64_t count, uint64_t* count_out) {
+    if (!net || !name) return tz_fail(TZ_EINVAL, "tz_net_get_tensor: null argument");
+    auto it = net->store.find(name);
+    if (it == net->store.end()) return tz_fail(TZ_EINVAL, std::string("tz_net_get_tensor: no tensor named ") + name);
+    if (count_out) *count_out = it->second.data.size();
+    if (out) {
+        if (count < it->second.data.size()) return tz_fail(TZ_EINVAL, "tz_net_get_tensor: buffer too small");
+        memcpy(out, it->second.data.data(), 4 * it->second.data.size());
+    }
+    return TZ_OK;
+}
+
+int tz_net_tensor_count(tz_net* net) { return net ? (int)net->store.size() : 0; }
+
+int tz_net_tensor_info(tz_net* net, int i, char* name_out, int name_cap, uint64_t* count_out) {
+    if (!net || i < 0 || i >= (int)net->store.size()) return tz_fail(TZ_EINVAL, "tz_net_tensor_info: index out of range");
+    auto it = net->store.begin();
+    std::advance(it, i);
+    if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", it->first.c_str());
+    if (count_out) *count_out = it->second.data.size();
+    return TZ_OK;
+}
+
+// Network::new(device, seed) (network/mod.rs:11; net5.rs:152-170): tch's default initialisers - conv / linear weights
+// Kaiming-uniform(a = sqrt 5) = U(+-1/sqrt(fan_in)), biases U(+-1/sqrt(fan_in)), BatchNorm weight U(0,1), bias 0, running
+// statistics 0 / 1, RND min 0 / max 1 (net5.rs:166-168), simhash_matrix N(0,1).  The draws come from a counter-based
+// generator keyed by (seed, tensor name): tch's own stream (torch's Philox/mt19937 through manual_seed) is not reproduced.
+namespace {
+uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct InitRng {
+    uint64_t key, ctr = 0;
+    InitRng(uint64_t seed, const std::string& name) : key(mix64(seed)) {
+        for (unsigned char c : name) key = mix64(key ^ c);
+    }
+    double uniform() { return (double)(mix64(key + (ctr++)) >> 11) * (1.0 / 9007199254740992.0); }
+    double normal() {
+        const double u = std::max(uniform(), 1e-300), v = uniform();
+        return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v);
+    }
+};
+void init_uniform(TensorStore& st, uint64_t seed, const std::string& name, std::vector<uint32_t> dims, double lo, double hi) {
+    HostTensor t;
+    t.dims = dims;
+    size_t n = 1;
+    for (auto d : dims) n *= d;
+    t.data.resize(n);
+    InitRng r(seed, name);
+    for (auto& x : t.data) x = (float)(lo + (hi - lo) * r.uniform());
+    st[name] = std::move(t);
+}
+void init_const(TensorStore& st, const std::string& name, uint32_t n, float v) {
+    HostTensor t;
+    t.dims = {n};
+    t.data.assign(n, v);
+    st[name] = std::move(t);
+}
+void init_conv(TensorStore& st, uint64_t seed, const std::string& p, uint32_t cout, uint32_t cin, uint32_t k, bool bias) {
+    const double b = 1.0 / sqrt((double)cin * k * k);
+    init_uniform(st, seed, p + ".weight", {cout, cin, k, k}, -b, b);
+    if (bias) init_uniform(st, seed, p + ".bias", {cout}, -b, b);
+}
+void init_linear(TensorStore& st, uint64_t seed, const std::string& p, uint32_t cout, uint32_t cin) {
+    const double b = 1.0 / sqrt((double)cin);
+    init_uniform(st, seed, p + ".weight", {cout, cin}, -b, b);
+    init_uniform(st, seed, p + ".bias", {cout}, -b, b);
+}
+void init_bn(TensorStore& st, uint64_t seed, const std::string& p, uint32_t c) {
+    init_uniform(st, seed, p + ".weight", {c}, 0.0, 1.0);
+    init_const(st, p + ".bias", c, 0.f);
+    init_const(st, p + ".running_mean", c, 0.f);
+    init_const(st, p + ".running_var", c, 1.f);
+}
+}  // namespace
+
+int tz_net_init_random(tz_net* net, uint64_t seed) {
+    if (!net) return tz_fail(TZ_EINVAL, "tz_net_init_random: null argument");
+    TensorStore st;
+    const uint32_t cin = net->cin, nn = net->nn;
+    init_conv(st, seed, "core.input_conv2d", FILTERS, cin, 3, false);
+    init_bn(st, seed, "core.batch_norm", FILTERS);
+    for (int b = 0; b < net->blocks; b++)
+        for (const char* half : {".a", ".b"}) {
+            const std::string p = "core.res_block_" + std::to_string(b) + half;
+            init_conv(st, seed, p + ".conv2d", FILTERS, FILTERS, 3, false);
+            init_bn(st, seed, p + ".batch_norm", FILTERS);
+        }
+    init_conv(st, seed, "policy.conv2d", net->pol_ch, FILTERS, 3, true);
+    for (const char* head : {"value", "ube"}) {
+        init_conv(st, seed, std::string(head) + ".conv2d", 1, FILTERS, 1, true);
+        init_linear(st, seed, std::string(head) + ".linear", 1, nn);
+    }
+    if (net->has_rnd) {
+        for (const char* r : {"rnd_learning", "rnd_target"}) {
+            init_linear(st, seed, std::string(r) + ".input_linear", 1024, cin * nn);
+            init_linear(st, seed, std::string(r) + ".hidden_linear", 1024, 1024);
+            init_linear(st, seed, std::string(r) + ".final_linear", 512, 1024);
+        }
+        init_const(st, "min", 1, 0.f);
+        init_const(st, "max", 1, 1.f);
+    }
+    if (net->has_hash) {
+        HostTensor t;
+        t.dims = {cin * nn, 32};
+        t.data.resize((size_t)cin * nn * 32);
+        InitRng r(seed, "simhash_matrix");
+        for (auto& x : t.data) x = (float)r.normal();
+        st["simhash_matrix"] = std::move(t);
+    }
+    return net_apply_store(net, std::move(st));
+}
+
+// Net::load on the root, then the same variables on every rank (selfplay/src/main.rs:107-121 for N shards): `status` is the
+// root's load result (0 = new model loaded, anything else = nothing new / unreadable: every rank keeps its weights), so all
+// ranks take the same branch.
+int tz_net_broadcast(tz_net* net, tz_comm* c, int root, int status) {
+    if (!net || !c) return tz_fail(TZ_EINVAL, "tz_net_broadcast: bad argument");
+    int rank = 0, world = 1;
+    int rc = tz_comm_info(c, &rank, &world, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (root < 0 || root >= world) return tz_fail(TZ_EINVAL, "tz_net_broadcast: bad root");
+    int64_t head[2] = {status, 0};
+    std::vector<unsigned char> blob;
+    if (rank == root && status == 0) {
+        if (!net->loaded) return tz_fail(TZ_ESTATE, "tz_net_broadcast: the root network has no weights");
+        tzw_dump(net->store, blob);
+        head[1] = (int64_t)blob.size();
+    }
+    rc = tz_comm_broadcast(c, head, sizeof head, root);
+    if (rc) return rc;
+    if (head[0] != 0) return TZ_OK;   // nothing to hand over
+    blob.resize((size_t)head[1]);
+    if ((rc = tz_comm_broadcast(c, blob.data(), blob.size(), root))) return rc;
+    if (rank == root) return TZ_OK;
+    return tz_net_load_weights_mem(net, blob.data(), blob.size());
+}
+
+int tz_weights_convert(const char* src, const char* dst) {
+    if (!src || !dst) return tz_fail(TZ_EINVAL, "tz_weights_convert: null argument");
+    TensorStore st;
+    int rc = weights_read_file(src, st);
+    if (rc) return rc;
+    return weights_write_file(dst, st);
 }
 
 // Diagnostic: time the residual-tower conv kernel (5x5, 256->256) on `positions` boards with an

@@ -83,6 +83,22 @@ class Trainer:
                 self.extra[name] = a.copy()
         return self
 
+    def load(self, path):
+        """Network::load on the trainer's VarStore (learn/src/main.rs:107-120): a LibTorch archive or a .tzw container."""
+        check(self.lib.tz_trainer_load(self.h, str(path).encode()))
+        return self
+
+    def save(self, path):
+        """Network::save (learn/src/main.rs:247-266): a LibTorch archive under tch's variable names (or .tzw), written natively."""
+        check(self.lib.tz_trainer_save(self.h, str(path).encode()))
+
+    def from_net(self, net):
+        check(self.lib.tz_trainer_from_net(self.h, net.h))
+        return self
+
+    def to_net(self, net):
+        check(self.lib.tz_trainer_to_net(self.h, net.h))
+
     def tensor(self, name, what=PARAM):
         out = np.zeros(self.names[name], np.float32)
         check(self.lib.tz_trainer_get_tensor(self.h, name.encode(), what, out.ctypes.data, out.size))

@@ -1,12 +1,16 @@
-"""Reading the reference's model files.  `learn` writes `model_latest.ot` / `model_NNNNNNN.ot` with tch's
-VarStore::save (takzero/src/network/mod.rs:16-18): a LibTorch `torch::serialize::OutputArchive` holding one
-named tensor per variable, names = VarStore paths joined with '.'.  PyTorch reads that archive with
-torch.jit.load.
+"""The reference's model files.  `learn` writes `model_latest.ot` / `model_NNNNNNN.ot` with tch's VarStore::save
+(takzero/src/network/mod.rs:16-18): a LibTorch `torch::serialize::OutputArchive` holding one named tensor per variable,
+names = VarStore paths joined with '.'.
 
-Name quirk (SURVEY.md §7, residual.rs:50-55): both SmallBlocks of a ResidualBlock are created under the same
+The library reads and writes that format natively (csrc/tz_ot.cpp: zip + the pickle subset LibTorch emits), so
+`load_ot` / `save_ot` here go through `tz_weights_convert` and need neither torch nor a compiler.  The LibTorch-based
+functions (`read_ot_libtorch` = torch.jit.load, `save_ot_libtorch` = the small C++ program over OutputArchive) are kept
+as the genuine reader / writer the tests cross-check the native code against.
+
+Name quirk (SURVEY.md 7, residual.rs:50-55): both SmallBlocks of a ResidualBlock are created under the same
 path, so the second one's five variables collide with the first one's and tch renames them
-`<path>__<number of variables registered so far>`.  This module maps   <name> -> `.a.`   and
-<name>__K -> `.b.`   whatever K is, which gives the names takzero_amd.weights / tz_net_load_weights use."""
+`<path>__<number of variables registered so far>`.  Readers map   <name> -> `.a.`   and   <name>__K -> `.b.`   whatever K
+is, which gives the names takzero_amd.weights / tz_net_load_weights use."""
 import os
 import re
 import subprocess
@@ -21,8 +25,9 @@ _SUFFIX = re.compile(r"^(.*)__(\d+)$")
 _BLOCK = re.compile(r"^(core\.res_block_\d+)\.(.+)$")
 
 
-def read_ot(path):
-    """name -> fp32 ndarray for every tensor of a LibTorch archive (needs torch; host-side tooling only)."""
+def read_ot_libtorch(path):
+    """name -> fp32 ndarray for every tensor of a LibTorch archive, read by LibTorch itself (torch.jit.load): the
+    cross-check of the native reader."""
     import torch
 
     m = torch.jit.load(str(path), map_location="cpu")
@@ -49,7 +54,18 @@ def canonical_names(named):
 
 
 def load_ot(path):
-    return canonical_names(read_ot(path))
+    """Canonical (`.a.` / `.b.`) name -> fp32 array, read by the library's own archive reader (tz_weights_convert)."""
+    from . import _lib
+    from .weights import load_tzw
+
+    with tempfile.TemporaryDirectory() as tmp:
+        flat = os.path.join(tmp, "model.tzw")
+        _lib.check(_lib.load().tz_weights_convert(str(path).encode(), flat.encode()))
+        return load_tzw(flat)
+
+
+def load_ot_libtorch(path):
+    return canonical_names(read_ot_libtorch(path))
 
 
 def tch_names(tensors):
@@ -66,8 +82,13 @@ def tch_names(tensors):
         out.append((final, tensors[key]))
         count += 1
 
+    # tch nn::batch_norm creates the affine pair before the running statistics; TZ_TCH_BN_ORDER=stats_first gives the older
+    # order (same switch as csrc/tz_ot.cpp ot_tch_names; not pinned by any file of the reference)
+    order = (("running_mean", "running_var", "weight", "bias") if os.environ.get("TZ_TCH_BN_ORDER") == "stats_first"
+             else ("weight", "bias", "running_mean", "running_var"))
+
     def bn(path, key):
-        for v in ("running_mean", "running_var", "weight", "bias"):  # tch nn::batch_norm creation order
+        for v in order:
             add("%s.%s" % (path, v), "%s.%s" % (key, v))
 
     add("core.input_conv2d.weight", "core.input_conv2d.weight")
@@ -102,8 +123,20 @@ def build_writer(force=False):
 
 
 def save_ot(path, tensors):
-    """Network::save (network/mod.rs:16-18): `tensors` by canonical (`.a.` / `.b.`) name -> LibTorch archive with
-    tch's variable names.  Written to a temporary file and renamed, so a reader never sees half a model."""
+    """Network::save (network/mod.rs:16-18): `tensors` by canonical (`.a.` / `.b.`) name -> LibTorch archive with tch's
+    variable names, written by the library's own writer to `<path>.part` and renamed (a reader never sees half a model)."""
+    from . import _lib
+    from .weights import save_tzw
+
+    with tempfile.TemporaryDirectory() as tmp:
+        flat = os.path.join(tmp, "model.tzw")
+        save_tzw(flat, tensors)
+        _lib.check(_lib.load().tz_weights_convert(flat.encode(), str(path).encode()))
+    return str(path)
+
+
+def save_ot_libtorch(path, tensors):
+    """The same through LibTorch's own OutputArchive (the small C++ program below): cross-check of the native writer."""
     exe = build_writer()
     path = str(path)
     with tempfile.TemporaryDirectory() as tmp:

@@ -7,8 +7,10 @@ process can sit on the other side of the same directory (SURVEY.md §8f rows 1-2
   targets-selfplay.txt, replays.txt, targets-reanalyze.txt   appended (selfplay/src/main.rs:332-366,
                          reanalyze/src/main.rs:230-243)
 
-With more than one rank each rank appends to its own files unless `gather` is set, in which case the targets are
-all-gathered (takzero_amd.selfplay.all_gather_targets) and rank 0 writes them."""
+With more than one rank every rank appends to the SAME un-suffixed files, as the reference's N processes in one directory do
+(README.md:130): what a move finished goes out as one write() of whole lines on an O_APPEND descriptor, so ranks never
+interleave inside a line and `learn` / `reanalyze` read everybody's output.  With `gather` (Python driver) or a communicator
+(native driver, NativeSelfPlay.set_comm) the targets are all-gathered first and rank 0 alone writes them."""
 import os
 import time
 
@@ -32,6 +34,10 @@ def _lib_error():
 def read_buffer_lengths(directory):
     with open(os.path.join(directory, "buffer_lengths.txt")) as f:
         return formats.parse_buffer_lengths(f.read())
+
+
+class ModelParseError(ValueError):
+    """model_latest.ot is there but does not parse (e.g. read while `learn` was writing it)."""
 
 
 class ModelWatcher:
@@ -80,13 +86,20 @@ class BroadcastModelWatcher(ModelWatcher):
 
                         tensors = weights.load_tzw(self.path)
                     self.stamp, changed = stamp, 1
-            except Exception as e:   # the other ranks must not be left waiting in the collective
+            except OSError as e:     # missing / unreadable file: every rank retries (selfplay/src/main.rs:116-119)
                 err, changed = e, -1
+            except Exception as e:   # an archive that does not parse (torn write): every rank keeps its net (:112-115)
+                err, changed = e, -2
+                self.stamp = stamp   # not looked at again until the file changes
         dev = self.device if self.device is not None else "cpu"
         flag = torch.tensor([changed], dtype=torch.int64, device=dev)
         dist.broadcast(flag, src=0)
-        if int(flag.item()) < 0:
-            raise err if err is not None else OSError("rank 0 could not read the model")
+        # the same exception class on every rank, so that all of them take the same branch in the callers and the next
+        # collective matches (rank 0 re-raising a parse error while the others raised OSError hung the job)
+        if int(flag.item()) == -1:
+            raise OSError("rank 0 could not read the model: %s" % (err if err is not None else "see rank 0"))
+        if int(flag.item()) == -2:
+            raise ModelParseError("rank 0 could not parse the model: %s" % (err if err is not None else "see rank 0"))
         if int(flag.item()) == 0:
             return False
         if self.rank == 0:
@@ -195,10 +208,20 @@ class AsyncAppender:
 
 
 def append_lines(path, lines):
+    """OpenOptions::append(true).create(true) + one write of everything: several processes append to the same file
+    (one per GPU here, 10 selfplay + 10 reanalyze processes in the reference's deployment) and a reader must never see
+    two writers' bytes interleaved inside a line."""
     if not lines or not any(lines):
         return
-    with open(path, "a") as f:  # OpenOptions::append(true).create(true)
-        f.write("".join(lines))
+    data = "".join(lines)
+    data = data.encode() if isinstance(data, str) else data
+    fd = os.open(path, os.O_WRONLY | os.O_APPEND | os.O_CREAT, 0o644)
+    try:
+        view = memoryview(data)
+        while len(view):                     # a regular file takes it whole; loop only for the sake of the contract
+            view = view[os.write(fd, view):]
+    finally:
+        os.close(fd)
 
 
 def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, world=1, search="gumbel",
@@ -215,7 +238,7 @@ def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, wor
         from .selfplay import NativeSelfPlay
 
         if gather:
-            raise ValueError("native run writes per-rank files; gather the files' consumers instead")
+            raise ValueError("native run: hand the shards a communicator instead (NativeSelfPlay.set_comm), rank 0 then writes")
         sp = NativeSelfPlay(mcts, sims_per_move, seed=seed, shard=rank, search=search, sampled_actions=sampled_actions,
                             exploration=exploration)
         watcher = None
@@ -243,7 +266,7 @@ def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, wor
                     return
 
         try:
-            sp.run(directory, moves=moves, max_buffer_len=MAX_SELFPLAY_BUFFER_LEN, suffix="" if world == 1 else "-rank%d" % rank,
+            sp.run(directory, moves=moves, max_buffer_len=MAX_SELFPLAY_BUFFER_LEN, suffix="",
                    reload=reload if watcher is not None else None, wait_limit_s=-1.0 if max_wait is None else float(max_wait))
         except _lib_error() as e:
             if e.code == -6:   # TZ_ESTATE: buffer_lengths.txt stayed unreadable / over the cap for max_wait
@@ -260,17 +283,15 @@ def run_selfplay(directory, mcts, sims_per_move, moves=None, seed=0, rank=0, wor
     if watch_model:
         watcher = BroadcastModelWatcher(mcts.agent, directory, rank) if broadcast_model and world > 1 else \
             ModelWatcher(mcts.agent, directory)
-    suffix = "" if world == 1 or gather else "-rank%d" % rank
-    rsuffix = "" if world == 1 else "-rank%d" % rank
     writer = AsyncAppender()
 
     def write(targets, replays, expl):
+        # every rank appends to the shared files (one write per move); with `gather` rank 0 holds everybody's targets
         if not gather or rank == 0:
-            append_lines(os.path.join(directory, "targets-selfplay%s.txt" % suffix), [formats.format_targets(n, targets)])
-        append_lines(os.path.join(directory, "replays%s.txt" % rsuffix), [formats.format_replay(n, *r) for r in replays])
+            append_lines(os.path.join(directory, "targets-selfplay.txt"), [formats.format_targets(n, targets)])
+        append_lines(os.path.join(directory, "replays.txt"), [formats.format_replay(n, *r) for r in replays])
         if exploration:
-            append_lines(os.path.join(directory, "replays-exploration%s.txt" % rsuffix),
-                         [formats.format_replay(n, *r) for r in expl])
+            append_lines(os.path.join(directory, "replays-exploration.txt"), [formats.format_replay(n, *r) for r in expl])
 
     step = 0
     try:
@@ -312,7 +333,7 @@ def run_reanalyze(directory, mcts, sims, iterations=None, seed=0, rank=0, world=
                     time.sleep(sleep)
 
         try:
-            nra.run(directory, iterations=iterations, min_positions=min_positions, suffix="" if world == 1 else "-rank%d" % rank,
+            nra.run(directory, iterations=iterations, min_positions=min_positions, suffix="",
                     reload=reload if watcher is not None else None, wait_limit_s=-1.0 if max_wait is None else float(max_wait))
         except _lib_error() as e:
             if e.code == -6:
@@ -321,11 +342,10 @@ def run_reanalyze(directory, mcts, sims, iterations=None, seed=0, rank=0, world=
         return nra
     ra = Reanalyze(mcts, sims, seed=seed, rank=rank, world=world, search=search, sampled_actions=sampled_actions)
     watcher = ModelWatcher(mcts.agent, directory) if watch_model else None
-    suffix = "" if world == 1 else "-rank%d" % rank
     it = 0
     t0 = time.monotonic()
     writer = AsyncAppender()
-    path = os.path.join(directory, "targets-reanalyze%s.txt" % suffix)
+    path = os.path.join(directory, "targets-reanalyze.txt")   # shared by all ranks (one write per iteration)
     try:
         while iterations is None or it < iterations:
             wait_until_needed(directory, 1, MAX_REANALYZE_BUFFER_LEN, watcher, sleep, max_wait, log)

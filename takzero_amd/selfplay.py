@@ -263,6 +263,19 @@ class NativeSelfPlay:
 
         _lib.check(self.lib.tz_selfplay_play_move(self.h))
 
+    def set_comm(self, comm, writer_rank=0):
+        """N shards (tz_selfplay_set_comm): after every play_move, `exchange()` gathers all ranks' finished targets and
+        replays; rank `writer_rank` (every rank if < 0) then holds everybody's lines for take_text / run."""
+        from . import _lib
+
+        _lib.check(self.lib.tz_selfplay_set_comm(self.h, comm.h if comm is not None else None, writer_rank))
+        self._comm = comm   # keep the communicator alive as long as the driver refers to it
+
+    def exchange(self):
+        from . import _lib
+
+        _lib.check(self.lib.tz_selfplay_exchange(self.h))
+
     def counters(self):
         import ctypes as C
 

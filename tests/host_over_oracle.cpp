@@ -3,6 +3,9 @@
 // driver code, same seed => the text it produces over the oracle must equal, byte for byte, what it produces over the
 // GPU engine (tests/test_gpu_native_driver.py); and being pure CPU code it also runs under ASan / UBSan.
 //   host_over_oracle <n> <half_komi> <agent 1|2> <batch> <kind 0|1|2> <sims> <k> <exploration> <moves> <seed> <out prefix>
+// Environment: TZH_SHARD = the shard index of the driver's random stream (default 0); TZH_COMM_DIR + TZH_RANK + TZH_WORLD
+// (+ TZH_WRITER, default 0) = N such processes exchanging through the "fs" transport of csrc/tz_comm.cpp after every move
+// (only the self-play part runs then); TZH_MARK = 1 writes a "#move" line after every move into the dumps.
 // With -DTZ_HARNESS_WITH_NET (GPU box only, linked against libtakzero_hip.so) agent 0 = the HIP network called through
 // tz_net_eval as the oracle search's Agent; four more arguments: <model.tzw> <arch> <blocks> <precision>.
 #include <cstdio>
@@ -85,16 +88,31 @@ int main(int argc, char** argv) {
 #endif
     tzo_search* s = tzo_search_create(agent, fn, user, B, n, hk);
     tz_selfplay* sp = nullptr;
-    if (tz_selfplay_create(s, sims, seed, 0, kind, k, exploration, &sp)) return 3;
+    const int shard = getenv("TZH_SHARD") ? atoi(getenv("TZH_SHARD")) : 0;
+    const bool mark = getenv("TZH_MARK") != nullptr;
+    if (tz_selfplay_create(s, sims, seed, shard, kind, k, exploration, &sp)) return 3;
+    tz_comm* comm = nullptr;
+    if (getenv("TZH_COMM_DIR")) {
+        if (tz_comm_create_fs(getenv("TZH_COMM_DIR"), atoi(getenv("TZH_RANK")), atoi(getenv("TZH_WORLD")), 120.0, &comm) ||
+            tz_selfplay_set_comm(sp, comm, getenv("TZH_WRITER") ? atoi(getenv("TZH_WRITER")) : 0)) {
+            fprintf(stderr, "comm: %s\n", tz_last_error());
+            return 11;
+        }
+    }
     std::string targets, replays, expl;
     for (int m = 0; m < moves; m++) {
-        if (tz_selfplay_play_move(sp)) {
+        if (tz_selfplay_play_move(sp) || tz_selfplay_exchange(sp)) {
             fprintf(stderr, "play_move: %s\n", tz_last_error());
             return 4;
         }
         targets += sp->targets_text;
         replays += sp->replays_text;
         expl += sp->exploration_text;
+        if (mark) {
+            targets += "#move\n";
+            replays += "#move\n";
+            expl += "#move\n";
+        }
         sp->targets_text.clear();
         sp->replays_text.clear();
         sp->exploration_text.clear();
@@ -103,6 +121,14 @@ int main(int argc, char** argv) {
     dump(prefix + ".replays", replays);
     dump(prefix + ".exploration", expl);
     tz_selfplay_destroy(sp);
+    if (comm) {
+        uint64_t collectives = 0, bytes = 0;
+        tz_comm_info(comm, nullptr, nullptr, nullptr, &collectives, &bytes);
+        printf("positions 0 collectives %llu bytes %llu\n", (unsigned long long)collectives, (unsigned long long)bytes);
+        tz_comm_destroy(comm);
+        tzo_search_destroy(s);
+        return 0;
+    }
     // reanalyze over what was just played (searches from fresh trees, so it is independent of the loop above)
     tz_reanalyze* ra = nullptr;
     if (tz_reanalyze_create(s, kind == 1 ? sims : 32, seed + 1, 0, 1, kind == 1 ? 1 : 0, k, &ra)) return 5;

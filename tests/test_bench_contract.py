@@ -50,6 +50,10 @@ def test_two_rank_launch_as_the_driver_does_it():
     assert len(lines) == 1, r.stdout[-800:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    # the line says what carried the exchange: here the rehearsal switches (gloo process group, shared-directory transport)
+    assert out["backend"] == "gloo" and out["world"] == 2
+    assert out["exchange"]["transport"] == "fs" and out["exchange"]["world"] == 2 and out["exchange"]["collectives"] == 3 * 3
+    assert out["targets_gathered"] >= 0
     # whole-job aggregate: 2 ranks x 128 games x 33 simulate calls per move x 2 timed moves
     assert abs(out["value"] * out["ms_per_step"] * 2 / 1000.0 - 2 * 128 * 33 * 2) < 0.02 * 2 * 128 * 33 * 2
 
@@ -64,3 +68,23 @@ def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_requested_rccl_that_cannot_form_is_a_failed_run_not_a_fallback():
+    """ADVICE r1 / VERDICT r1 #2a: `--gpus 2` with the default backend (nccl = RCCL) where RCCL cannot come up (this
+    container has no GPU) must end non-zero with the reason on stderr and print no JSON line: a SCALE record can then never
+    show a number that a silent gloo fallback produced."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU: on the GPU box two ranks would contend for one device")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TZ_BENCH_BACKEND", "TZ_BENCH_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--games", "16",
+           "--sims", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "backend nccl (RCCL) requested and unavailable" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

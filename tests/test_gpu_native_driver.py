@@ -160,36 +160,123 @@ def test_native_reanalyze_feeds_samples_and_writes_targets(oracle, tmp_path):
         R.run_reanalyze(d, mcts, 16, iterations=1, watch_model=False, native=True, min_positions=64, max_wait=0.1)
 
 
-def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
-    """examples/selfplay_cli.cpp: the selfplay binary as a plain C++ program linked against libtakzero_hip.so — no
-    Python, no torch in the process.  It must produce the same kind of files, and pick up a new model_latest.tzw."""
+def _build_example(tmp_path, name):
     import subprocess
 
-    A = require_gpu()
     from takzero_amd import _lib
-    from takzero_amd import formats as F
-    from takzero_amd import weights as W
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "selfplay_cli")
-    r = subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(root, "examples", "selfplay_cli.cpp"), "-I" + os.path.join(root, "include"),
+    exe = str(tmp_path / name)
+    r = subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(root, "examples", name + ".cpp"), "-I" + os.path.join(root, "include"),
                         "-L" + os.path.dirname(_lib.LIB_PATH), "-ltakzero_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", exe],
                        capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("cannot build the example here: " + r.stderr[-300:])
+    return exe
+
+
+def _fields(stdout):
+    return dict(zip(stdout.split()[::2], stdout.split()[1::2]))
+
+
+def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
+    """examples/selfplay_cli.cpp: the selfplay binary as a plain C++ program linked against libtakzero_hip.so — no
+    Python, no torch in the process.  It must produce the same kind of files, and pick up a new model_latest.ot (the
+    LibTorch archive the reference's learn writes: read by the library itself)."""
+    import subprocess
+
+    A = require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    exe = _build_example(tmp_path, "selfplay_cli")
     d, n = str(tmp_path), 4
     W.save_tzw(os.path.join(d, "start.tzw"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=7))
-    W.save_tzw(os.path.join(d, "model_latest.tzw"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
+    ot.save_ot(os.path.join(d, "model_latest.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
     open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
     r = subprocess.run([exe, "--directory", d, "--model", os.path.join(d, "start.tzw"), "--arch", "100", "--n", str(n), "--blocks", "1",
                         "--games", "48", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel", "--moves", "60", "--wait-limit", "5"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
-    fields = dict(zip(r.stdout.split()[::2], r.stdout.split()[1::2]))
+    fields = _fields(r.stdout)
     assert fields["moves"] == "60" and fields["model_reloads"] == "1" and int(fields["replays"]) > 0
     targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
     replays = open(os.path.join(d, "replays.txt"), "rb").read()
     assert targets.count(b"\n") == int(fields["targets"]) and replays.count(b"\n") == int(fields["replays"])
+    _check_lines(oracle, n, targets, replays, "gumbel")
+
+
+def test_closed_loop_of_the_two_cpp_programs_over_ot_files(oracle, tmp_path):
+    """learn_cli (tz_learn_run with its own save points) writes model_0000000.ot, model_<pre>.ot and
+    model_latest.ot as LibTorch archives; selfplay_cli (started from Net::new) reloads model_latest.ot while it plays and feeds
+    learn's buffer through targets-selfplay.txt — the reference's three-file protocol between two C++ processes, no Python,
+    no torch, no LibTorch in either.  The archives are then read back by LibTorch itself (torch.jit.load)."""
+    import subprocess
+    import time
+
+    require_gpu()
+    from takzero_amd import ot
+
+    learn, selfplay = _build_example(tmp_path, "learn_cli"), _build_example(tmp_path, "selfplay_cli")
+    d, n = str(tmp_path / "run"), 4
+    os.makedirs(d)
+    common = ["--arch", "100", "--n", str(n), "--blocks", "1"]
+    lp = subprocess.Popen([learn, "--directory", d, "--batch", "64", "--steps", "90", "--seed", "5", "--pre-training-steps", "20",
+                           "--initial-targets", "2000", "--min-selfplay", "300", "--steps-per-save", "30", "--steps-per-checkpoint", "60",
+                           "--steps-before-reanalyze", "100000", "--read-interval", "0.2", "--sleep", "0.2", "--wait-limit", "240"] + common,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not os.path.exists(os.path.join(d, "buffer_lengths.txt")) and time.time() - t0 < 120 and lp.poll() is None:
+        time.sleep(0.1)
+    assert os.path.exists(os.path.join(d, "buffer_lengths.txt")), lp.communicate()[1][-1500:]
+    sp = subprocess.run([selfplay, "--directory", d, "--games", "64", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel",
+                         "--moves", "150", "--wait-limit", "60", "--seed", "9"] + common, capture_output=True, text=True, timeout=600)
+    lout, lerr = lp.communicate(timeout=600)
+    assert sp.returncode == 0, (sp.stdout, sp.stderr[-1500:])
+    assert lp.returncode == 0, (lout, lerr[-1500:])
+    lf, sf = _fields(lout), _fields(sp.stdout)
+    assert lf["model_steps"] == "110" and lf["starting_steps"] == "20" and lf["rc"] == "0"
+    assert int(sf["model_reloads"]) >= 2 and sf["moves"] == "150"     # the initial model_latest.ot and at least one save point
+    names = sorted(f for f in os.listdir(d) if f.endswith(".ot"))
+    assert names == ["model_0000000.ot", "model_0000020.ot", "model_0000060.ot", "model_latest.ot"], names
+    assert not [f for f in os.listdir(d) if f.endswith(".part")]
+    first, last = ot.load_ot_libtorch(os.path.join(d, "model_0000000.ot")), ot.load_ot_libtorch(os.path.join(d, "model_latest.ot"))
+    assert set(first) == set(last) == set(ot.load_ot(os.path.join(d, "model_latest.ot")))
+    assert not np.array_equal(first["core.res_block_0.b.conv2d.weight"], last["core.res_block_0.b.conv2d.weight"])   # it trained
+    assert not np.array_equal(first["core.batch_norm.running_mean"], last["core.batch_norm.running_mean"])
+    targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
+    replays = open(os.path.join(d, "replays.txt"), "rb").read()
+    _check_lines(oracle, n, targets, replays, "gumbel")
+
+
+def test_two_shards_of_the_cpp_program_hand_over_to_rank_0(oracle, tmp_path):
+    """N shards natively (VERDICT r1 #2b): two selfplay_cli processes (both on this box's one GPU, "fs" transport — on a node
+    it is one process per GPU over RCCL, same code above the transport) exchange after every move; rank 0 appends
+    everybody's targets and replays to the un-suffixed files `learn` and `reanalyze` read, rank 1 writes nothing."""
+    import subprocess
+
+    require_gpu()
+    from takzero_amd import formats as F
+
+    exe = _build_example(tmp_path, "selfplay_cli")
+    d, n = str(tmp_path / "run"), 4
+    os.makedirs(d)
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    os.makedirs(tmp_path / "xch")
+    procs = [subprocess.Popen([exe, "--directory", d, "--arch", "100", "--n", str(n), "--blocks", "1", "--games", "32", "--sims", "16",
+                               "--sampled-actions", "4", "--search", "gumbel", "--moves", "70", "--wait-limit", "30", "--seed", "3",
+                               "--rank", str(r), "--world", "2", "--comm", "fs", "--comm-dir", str(tmp_path / "xch"), "--device", "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1200:] for o in outs]
+    f0, f1 = _fields(outs[0][0]), _fields(outs[1][0])
+    targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
+    replays = open(os.path.join(d, "replays.txt"), "rb").read()
+    assert int(f0["targets"]) > 0 and int(f1["targets"]) > 0 and f0["targets"] != f1["targets"]   # two different shards
+    assert targets.count(b"\n") == int(f0["targets"]) + int(f1["targets"])
+    assert replays.count(b"\n") == int(f0["replays"]) + int(f1["replays"])
+    assert sorted(os.listdir(d)) == ["buffer_lengths.txt", "replays.txt", "targets-selfplay.txt"]
     _check_lines(oracle, n, targets, replays, "gumbel")
 
 

@@ -217,36 +217,72 @@ def test_simhash_indices_counts_and_bitvec_file(oracle, tmp_path):
 
 
 def test_network_lifecycle_new_save_load_partial_clone(oracle, tmp_path):
-    """Network::{new, save, load, load_partial, clone} (network/mod.rs:10-45)."""
+    """Network::{new, save, load, load_partial, clone} (network/mod.rs:10-45) at the C ABI (tz_net_init_random, tz_net_save,
+    tz_net_load_weights, tz_net_load_partial, tz_net_clone): no Python-side copy of the variables is involved."""
     A = require_gpu()
     from takzero_amd import ot
     from takzero_amd import weights as W
 
-    try:
-        ot.build_writer()
-    except RuntimeError as e:
-        pytest.skip(str(e))
     n, blocks = 4, 1
     a = A.Net.new(arch=A.ARCH_TEST, seed=5, n=n, blocks=blocks)
+    assert set(a.tensors()) == set(W.init_weights(W.ARCH_TEST, n=n, blocks=blocks))
+    b5 = A.Net.new(arch=A.ARCH_TEST, seed=5, n=n, blocks=blocks)
+    b6 = A.Net.new(arch=A.ARCH_TEST, seed=6, n=n, blocks=blocks)
     states = O.states_array(random_positions(oracle, O, n, 4, 6, 3))
     want = a.forward_raw(states)
+    assert all(np.array_equal(x, y) for x, y in zip(b5.forward_raw(states), want))        # new(seed) is a function of the seed
+    assert not np.array_equal(b6.forward_raw(states)[0], want[0])
+    t = a.tensors()
+    bound = 1.0 / np.sqrt(256 * 9)      # tch's defaults: Kaiming-uniform(a = sqrt 5) = U(+-1/sqrt(fan_in)); BN weight U(0,1), stats 0 / 1
+    cw = t["core.res_block_0.a.conv2d.weight"]
+    assert np.abs(cw).max() <= bound and np.abs(cw).max() > 0.98 * bound and abs(float(cw.mean())) < 1e-3
+    assert 0 <= t["core.batch_norm.weight"].min() and t["core.batch_norm.weight"].max() <= 1 and np.all(t["core.batch_norm.running_var"] == 1)
     a.save(tmp_path / "model_0000000.ot")
     a.save(tmp_path / "model.tzw")
+    assert sorted(os.listdir(tmp_path)) == ["model.tzw", "model_0000000.ot"]            # no .part left behind
     for path in ("model_0000000.ot", "model.tzw"):
         b = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load(tmp_path / path)
         assert all(np.array_equal(x, y) for x, y in zip(b.forward_raw(states), want)), path
+    # what tz_net_save wrote is a LibTorch archive under tch's variable names: LibTorch's own reader agrees
+    named = ot.read_ot_libtorch(tmp_path / "model_0000000.ot")
+    assert "core.res_block_0.conv2d.weight__10" in named and np.array_equal(named["policy.conv2d.bias"], t["policy.conv2d.bias"])
     c = a.clone(0)
     assert all(np.array_equal(x, y) for x, y in zip(c.forward_raw(states), want))
     # load_partial: a file without the policy head leaves that head as it was and reports it
-    other = W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=6)
+    other = b6.tensors()
+    other = {k: v.reshape(np.shape(W.init_weights(W.ARCH_TEST, n=n, blocks=blocks)[k])) for k, v in other.items()}
     partial = {k: v for k, v in other.items() if not k.startswith("policy.")}
     W.save_tzw(tmp_path / "partial.tzw", partial)
     missing = a.load_partial(tmp_path / "partial.tzw")
     assert sorted(missing) == ["policy.conv2d.bias", "policy.conv2d.weight"]
     mixed = dict(other)
-    mixed.update({k: v for k, v in W.init_weights(W.ARCH_TEST, n=n, blocks=blocks, seed=5).items() if k.startswith("policy.")})
+    mixed.update({k: v.reshape(np.shape(other[k])) for k, v in t.items() if k.startswith("policy.")})
     d = A.Net(arch=A.ARCH_TEST, n=n, blocks=blocks).load_tensors(mixed)
     assert all(np.array_equal(x, y) for x, y in zip(a.forward_raw(states), d.forward_raw(states)))
+    assert all(np.array_equal(x, y) for x, y in zip(c.forward_raw(states), want))        # the clone has its own variables
+    # a failed load (truncated archive) leaves the weights alone
+    blob = open(tmp_path / "model_0000000.ot", "rb").read()
+    open(tmp_path / "torn.ot", "wb").write(blob[:len(blob) // 3])
+    with pytest.raises(A.TakzeroError):
+        c.load(tmp_path / "torn.ot")
+    assert all(np.array_equal(x, y) for x, y in zip(c.forward_raw(states), want))
+
+
+def test_simhash_net_saves_and_loads_its_set_beside_the_model(oracle, tmp_path):
+    """net6_simhash.rs:152-190: Network::save writes bitvec.bin beside the .ot, Network::load reads it back; clone copies it."""
+    A = require_gpu()
+
+    a = A.Net.new(arch=A.ARCH_NET4_SIMHASH, seed=2)
+    states = O.states_array(random_positions(oracle, O, 4, 4, 16, 5, max_ply=20))
+    acts = [O.possible_moves(oracle, s) for s in states]
+    a.hash_indices(states[:8], update=True)
+    var = a.policy_value_uncertainty(states, acts)[2]
+    assert np.any(var < 4.0) and np.any(var == 4.0)
+    a.save(tmp_path / "model_latest.ot")
+    assert (tmp_path / "bitvec.bin").stat().st_size == 1 << 29
+    b = A.Net(arch=A.ARCH_NET4_SIMHASH).load(tmp_path / "model_latest.ot")
+    assert np.array_equal(b.policy_value_uncertainty(states, acts)[2], var)
+    assert np.array_equal(a.clone(0).policy_value_uncertainty(states, acts)[2], var)
 
 
 @pytest.mark.gpu

@@ -41,3 +41,44 @@ def test_native_drivers_over_the_oracle_under_sanitizers(harness, tmp_path, kind
         assert out["exploration"] and all(len(line.split()) <= 15 for line in out["exploration"].decode().splitlines())
     if kind != 2 and out["positions"] >= 24:
         assert out["reanalyze"].count(b"\n") == 48   # two iterations of one target per position
+
+
+@pytest.mark.parametrize("kind,sims,k,exploration,agent,writer", [(1, 16, 4, 1, 2, 0), (0, 12, 64, 0, 1, -1)])
+def test_two_shards_exchange_packed_targets_like_one_directory(harness, tmp_path, kind, sims, k, exploration, agent, writer):
+    """N shards, world 2, no GPU: two processes of the native self-play driver (over the oracle search, under
+    ASan + UBSan) hand over after every move through csrc/tz_comm.cpp — all-gather of counts, then of the packed target
+    records and of the replay lines ("fs" transport: same packing and ordering code as under RCCL).  Move by move the writer
+    rank must hold exactly what the two shards produce on their own, rank 0's lines first: the reference's N selfplay
+    processes appending to one directory (selfplay/src/main.rs:332-366), minus the interleaving."""
+    import subprocess
+
+    from host_oracle_util import command
+
+    n, B, moves, seed = 4, 16, 45, 21
+    solo = [run(harness, tmp_path / ("solo%d" % r), n, 4, agent, B, kind, sims, k, exploration, moves, seed,
+                env={"TZH_SHARD": str(r), "TZH_MARK": "1"}, parts=("targets", "replays", "exploration")) for r in (0, 1)]
+    xdir = tmp_path / "xch"
+    xdir.mkdir()
+    import os
+
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TZH_SHARD=str(r), TZH_MARK="1", TZH_COMM_DIR=str(xdir), TZH_RANK=str(r),
+                   TZH_WORLD="2", TZH_WRITER=str(writer))
+        procs.append(subprocess.Popen(command(harness, tmp_path / ("rank%d" % r), n, 4, agent, B, kind, sims, k, exploration, moves, seed),
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    fields = dict(zip(outs[0][0].split()[::2], outs[0][0].split()[1::2]))
+    assert int(fields["collectives"]) == 3 * moves and int(fields["bytes"]) > 0
+    left = list(xdir.glob("xch-*"))                        # the transport cleans up after itself, bar the closing round's 8 bytes per rank
+    assert len(left) == 2 and all(p.stat().st_size == 8 for p in left)
+    for part in ("targets", "replays", "exploration"):
+        got = [open("%s.%s" % (tmp_path / ("rank%d" % r), part), "rb").read().split(b"#move\n") for r in (0, 1)]
+        want = [s[part].split(b"#move\n") for s in solo]
+        assert len(got[0]) == len(want[0]) == moves + 1
+        merged = [a + b for a, b in zip(want[0], want[1])]
+        keepers = (0, 1) if writer < 0 else (writer,)
+        for r in (0, 1):
+            assert got[r] == (merged if r in keepers else [b""] * (moves + 1)), (part, r)
+    assert solo[0]["targets"] != solo[1]["targets"] and solo[0]["targets"].count(b"\n") > moves   # the shards really differ

@@ -1,8 +1,15 @@
-"""The reference's `.ot` model files (tch VarStore::save = LibTorch OutputArchive): a real archive is written with
-LibTorch's C++ API under tch's variable names (incl. the `__K` suffix of the second SmallBlock) and read back."""
+"""The reference's `.ot` model files (tch VarStore::save = LibTorch OutputArchive, network/mod.rs:16-28).
+
+The library reads and writes them natively (csrc/tz_ot.cpp).  tch / LibTorch are not under /root/reference, so the format is
+pinned against the LibTorch of this image, both ways: archives written by LibTorch's own OutputArchive (the small C++
+program takzero_amd/csrc/ot_writer.cpp, i.e. what torch-sys' at_save_multi calls) are read by the native reader, archives
+written by the native writer are read by LibTorch's own reader (torch.jit.load), and the pickle program + code file of the
+two writers are compared byte for byte."""
+import os
+import zipfile
+
 import numpy as np
 import pytest
-
 
 
 @pytest.fixture(scope="module")
@@ -15,7 +22,13 @@ def ot_writer():
         pytest.skip(str(e))
 
 
-def test_ot_round_trip_through_libtorch(ot_writer, tmp_path):
+def _same(a, b):
+    assert set(a) == set(b)
+    for k in a:
+        assert np.asarray(b[k]).shape == np.asarray(a[k]).shape and np.array_equal(a[k], b[k]), k
+
+
+def test_native_reader_reads_what_libtorch_writes(ot_writer, tmp_path):
     from takzero_amd import ot
     from takzero_amd import weights as W
 
@@ -24,15 +37,129 @@ def test_ot_round_trip_through_libtorch(ot_writer, tmp_path):
     # the second SmallBlock of every ResidualBlock collides with the first one's path and gets `__K`
     assert "core.res_block_0.conv2d.weight" in names and any(n.startswith("core.res_block_0.conv2d.weight__") for n in names)
     assert len(set(names)) == len(names) == len(w)
-    path = ot.save_ot(tmp_path / "model_latest.ot", w)
+    path = ot.save_ot_libtorch(tmp_path / "model_latest.ot", w)
     assert not (tmp_path / "model_latest.ot.part").exists()
+    _same(w, ot.load_ot(path))            # native reader
+    _same(w, ot.load_ot_libtorch(path))   # LibTorch's own reader agrees
+
+
+def test_libtorch_reads_what_the_native_writer_writes(tmp_path):
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_TEST, n=4, blocks=2, seed=12, trained_stats=True)
+    path = ot.save_ot(tmp_path / "model_0000100.ot", w)
+    assert not (tmp_path / "model_0000100.ot.part").exists()
+    named = ot.read_ot_libtorch(path)     # torch.jit.load: the reader tch's VarStore::load goes through
+    assert list(named) == [n for n, _ in ot.tch_names(w)]      # tch's variable names, in creation order
+    _same(w, ot.canonical_names(named))
+    _same(w, ot.load_ot(path))
+
+
+def test_native_writer_emits_libtorchs_bytes(ot_writer, tmp_path):
+    """Same tensors through OutputArchive::save_to and through the native writer: identical data.pkl (opcodes, memo layout,
+    integer widths), identical code/__torch__.py and constants, identical storages."""
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_TEST, n=4, blocks=1, seed=3)     # 4-D, 2-D, 1-D and [1] shapes
+    big = W.init_weights(W.ARCH_NET5, seed=3)
+    w.update({k: big[k] for k in ("rnd_learning.final_linear.weight", "rnd_learning.final_linear.bias", "min", "max")})
+    w["simhash_matrix"] = W.init_weights(W.ARCH_NET4_SIMHASH, seed=3)["simhash_matrix"]
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    a = ot.save_ot_libtorch(tmp_path / "a" / "model.ot", w)
+    b = ot.save_ot(tmp_path / "b" / "model.ot", w)
+    za, zb = zipfile.ZipFile(a), zipfile.ZipFile(b)
+
+    def entry(z, suffix):
+        (name,) = [n for n in z.namelist() if n.endswith(suffix)]
+        return z.read(name)
+
+    for suffix in ("/data.pkl", "/code/__torch__.py", "/constants.pkl", "/version"):
+        assert entry(za, suffix) == entry(zb, suffix), suffix
+    for i in range(len(w)):
+        assert entry(za, "/data/%d" % i) == entry(zb, "/data/%d" % i)
+    assert zb.testzip() is None            # CRCs of the native zip
+
+
+def test_long_memo_indices_and_wide_integers(tmp_path):
+    """More than 256 memo slots (LONG_BINPUT / LONG_BINGET) and element counts beyond 16 bits: a full net5 store."""
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_NET5, seed=4)
+    assert w["min"].tolist() == [0.0] and w["max"].tolist() == [1.0]   # net5.rs:166-168
+    # net5.rs:327-347 `update_rnd_persistance`: the RND normalisation survives save / load, as do all 28.8 M parameters
+    w["min"] = np.float32([0.25])
+    w["max"] = np.float32([7.5])
+    path = ot.save_ot(tmp_path / "model_latest.ot", w)
     back = ot.load_ot(path)
-    assert set(back) == set(w)
-    for k in w:
-        assert back[k].shape == w[k].shape and np.array_equal(back[k], w[k]), k
+    assert back["min"].tolist() == [0.25] and back["max"].tolist() == [7.5]
+    _same(w, back)
+    named = ot.read_ot_libtorch(path)
+    assert len(named) == len(w) and np.array_equal(named["max"], w["max"])
+    assert np.array_equal(named["core.res_block_19.conv2d.weight__%d" % (5 + 19 * 10 + 5)], w["core.res_block_19.b.conv2d.weight"])
 
 
-def test_canonical_names_do_not_depend_on_the_suffix_number():
+def test_reader_accepts_other_pickle_dialects_and_strided_tensors(tmp_path):
+    """torch.jit.save of a Python-built module (named buffers, a transposed = non-contiguous parameter, fp64 and fp16
+    storages) and torch.save of a plain state dict (protocol-2 pickle from Python's pickler)."""
+    import torch
+
+    from takzero_amd import _lib
+    from takzero_amd.weights import load_tzw
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(1)
+            self.w = torch.nn.Parameter(torch.randn(5, 7, generator=g).t())          # strides (1, 7)
+            self.register_buffer("d", torch.randn(3, 2, generator=g, dtype=torch.float64))
+            self.register_buffer("h", torch.randn(4, generator=g).to(torch.float16))
+            self.register_buffer("v", torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)[:, 1:, ::2])
+
+        def forward(self, x):
+            return x
+
+    m = M()
+    torch.jit.script(m).save(str(tmp_path / "scripted.pt"))
+    torch.save({k: v for k, v in m.state_dict().items()}, str(tmp_path / "state.pt"))
+    want = {k: v.detach().to(torch.float32).numpy() for k, v in m.state_dict().items()}
+    for src in ("scripted.pt", "state.pt"):
+        _lib.check(_lib.load().tz_weights_convert(str(tmp_path / src).encode(), str(tmp_path / "out.tzw").encode()))
+        got = load_tzw(tmp_path / "out.tzw")
+        assert set(got) == set(want), src
+        for k in want:
+            assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), (src, k)
+
+
+def test_damaged_archives_are_parse_errors(tmp_path):
+    """A torn model file (learn writing while selfplay reads: selfplay/src/main.rs:112-119 keeps the old net) is TZ_EPARSE,
+    never a crash: truncations at every structural boundary and a flipped byte in the pickle."""
+    from takzero_amd import _lib, ot
+    from takzero_amd import weights as W
+
+    lib = _lib.load()
+    w = W.init_weights(W.ARCH_TEST, n=3, blocks=1, seed=2)
+    path = ot.save_ot(tmp_path / "model_latest.ot", w)
+    blob = open(path, "rb").read()
+    out = str(tmp_path / "x.tzw").encode()
+    for cut in (0, 3, 30, 100, len(blob) // 2, len(blob) - 300, len(blob) - 23, len(blob) - 1):
+        bad = tmp_path / "cut.ot"
+        bad.write_bytes(blob[:cut])
+        assert lib.tz_weights_convert(str(bad).encode(), out) == -2, cut
+    z = zipfile.ZipFile(path)
+    info = [i for i in z.infolist() if i.filename.endswith("/data.pkl")][0]
+    start = blob.index(b"\x80\x02c__torch__", info.header_offset)
+    for at, byte in ((start, b"\x01"), (start + 2, b"\x7f")):     # an unknown opcode in place of PROTO / GLOBAL
+        bad = tmp_path / "flip.ot"
+        bad.write_bytes(blob[:at] + byte + blob[at + 1:])
+        assert lib.tz_weights_convert(str(bad).encode(), out) == -2
+    assert lib.tz_weights_convert(str(tmp_path / "missing.ot").encode(), out) == -2
+
+
+def test_canonical_names_do_not_depend_on_the_suffix_number(tmp_path):
     from takzero_amd import ot
 
     a = np.zeros(1, np.float32)
@@ -44,10 +171,27 @@ def test_canonical_names_do_not_depend_on_the_suffix_number():
     assert c["core.res_block_3.b.conv2d.weight"][0] == 1
     with pytest.raises(ValueError):
         ot.canonical_names({"policy.conv2d.bias__3": a})
+    # the native reader applies the same rule: archives whose duplicates carry other numbers (the two creation orders of
+    # nn::batch_norm, TZ_TCH_BN_ORDER) map to the same `.a.` / `.b.` names
+    from takzero_amd import weights as W
+
+    w = W.init_weights(W.ARCH_TEST, n=3, blocks=1, seed=9, trained_stats=True)
+    os.environ["TZ_TCH_BN_ORDER"] = "stats_first"
+    try:
+        p1 = ot.save_ot(tmp_path / "stats_first.ot", w)
+        n1 = [n for n, _ in ot.tch_names(w)]
+    finally:
+        del os.environ["TZ_TCH_BN_ORDER"]
+    p2 = ot.save_ot(tmp_path / "affine_first.ot", w)
+    n2 = [n for n, _ in ot.tch_names(w)]
+    assert n1 != n2 and "core.res_block_0.batch_norm.running_mean__11" in n1 and "core.res_block_0.batch_norm.weight__11" in n2
+    assert list(ot.read_ot_libtorch(p1)) == n1 and list(ot.read_ot_libtorch(p2)) == n2
+    _same(w, ot.load_ot(p1))
+    _same(w, ot.load_ot(p2))
 
 
 @pytest.mark.gpu
-def test_net_load_ot_equals_load_tensors(ot_writer, tmp_path):
+def test_net_load_ot_equals_load_tensors(tmp_path):
     """Network::load (network/mod.rs:24-28) on a LibTorch archive gives the same network as the flat container."""
     import takzero_amd.api as tz
     from takzero_amd import weights as W
@@ -68,21 +212,3 @@ def test_net_load_ot_equals_load_tensors(ot_writer, tmp_path):
     for x, y in zip(ra, rb):
         assert np.array_equal(np.asarray(x), np.asarray(y))
     assert np.array_equal(a.hash_indices(states), b.hash_indices(states))
-
-
-def test_update_rnd_persistance(ot_writer, tmp_path):
-    """net5.rs:327-347 `update_rnd_persistance`: the RND normalisation (min / max variables of the VarStore) survives a
-    save / load of the full net5 archive, as do all 28.8 M parameters."""
-    from takzero_amd import ot
-    from takzero_amd import weights as W
-
-    w = W.init_weights(W.ARCH_NET5, seed=4)
-    assert w["min"].tolist() == [0.0] and w["max"].tolist() == [1.0]   # net5.rs:166-168
-    w["min"] = np.float32([0.25])
-    w["max"] = np.float32([7.5])
-    path = ot.save_ot(tmp_path / "model_latest.ot", w)
-    back = ot.load_ot(path)
-    assert back["min"].tolist() == [0.25] and back["max"].tolist() == [7.5]
-    assert set(back) == set(w) and sum(v.size for v in back.values()) == sum(v.size for v in w.values())
-    for k in ("rnd_target.final_linear.weight", "core.res_block_19.b.batch_norm.running_var", "policy.conv2d.bias"):
-        assert np.array_equal(back[k], w[k]), k
