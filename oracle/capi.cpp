@@ -410,3 +410,77 @@ int tzo_kat_safecrack(int visits) {
 }
 
 }  // extern "C"
+
+// ---- the decisions above the search (oracle/host.hpp), attached to a tzo_search: tests/host_over_oracle.cpp lets the
+// product's native drivers run over this search and checks every decision they take against these ----
+#include "host.hpp"
+
+struct tzo_host {
+    tzo_search* s;
+    SelfplayHost sp;
+    std::vector<CompleteTarget> done;
+    explicit tzo_host(tzo_search* search) : s(search), sp(search->mcts->batch()) {}
+};
+
+extern "C" {
+
+tzo_host* tzo_host_create(tzo_search* s) { return new tzo_host(s); }
+void tzo_host_destroy(tzo_host* h) { delete h; }
+
+// expected actions (0xFFFF for a root without children) and whether each game consumed its draw; then take_a_step's record
+int tzo_host_choose_and_record(tzo_host* h, int kind, const uint16_t* halving, const double* draws, float visitations, uint16_t* expected_out,
+                               uint8_t* sampled_out) {
+    const size_t B = h->s->mcts->batch();
+    std::vector<int> hv(B), out;
+    std::vector<double> d(draws, draws + B);
+    std::vector<uint8_t> sampled;
+    for (size_t g = 0; g < B; g++) hv[g] = halving[g];
+    h->sp.choose(*h->s->mcts, kind, hv, d, out, sampled);
+    for (size_t g = 0; g < B; g++) {
+        expected_out[g] = out[g] < 0 ? 0xFFFF : (uint16_t)out[g];
+        sampled_out[g] = sampled[g];
+    }
+    h->sp.record(*h->s->mcts, kind, visitations);
+    return 0;
+}
+
+// restart_envs_and_complete_targets for the games in `terminal`; returns the number of completed targets, kept for tzo_host_target
+int tzo_host_complete(tzo_host* h, const int8_t* terminal, const float* betas) {
+    const size_t B = h->s->mcts->batch();
+    std::vector<int> t(B);
+    std::vector<float> b(betas, betas + B);
+    for (size_t g = 0; g < B; g++) t[g] = terminal[g];
+    h->done.clear();
+    h->sp.complete(t, b, h->done);
+    return (int)h->done.size();
+}
+
+int tzo_host_target(tzo_host* h, int i, tz_state* state_out, int amax, uint16_t* moves_out, float* policy_out, float* value_out, float* ube_out) {
+    if (i < 0 || i >= (int)h->done.size()) return -1;
+    const CompleteTarget& t = h->done[i];
+    if ((int)t.moves.size() > amax) return -1;
+    t.env.g.to_state(*state_out);
+    for (size_t k = 0; k < t.moves.size(); k++) {
+        moves_out[k] = (uint16_t)t.moves[k];
+        policy_out[k] = t.policy[k];
+    }
+    *value_out = t.value;
+    *ube_out = t.ube;
+    return (int)t.moves.size();
+}
+
+// reanalyze target of game g for the selected action (reanalyze/src/main.rs:184-203)
+int tzo_host_reanalyze_target(tzo_search* s, int g, uint16_t selected, int amax, uint16_t* moves_out, float* policy_out, float* value_out,
+                              float* ube_out) {
+    const CompleteTarget t = reanalyze_target(s->mcts->nodes[g], s->mcts->envs[g], (int)selected);
+    if ((int)t.moves.size() > amax) return -1;
+    for (size_t k = 0; k < t.moves.size(); k++) {
+        moves_out[k] = (uint16_t)t.moves[k];
+        policy_out[k] = t.policy[k];
+    }
+    *value_out = t.value;
+    *ube_out = t.ube;
+    return (int)t.moves.size();
+}
+
+}  // extern "C"

@@ -11,6 +11,7 @@
 // A second transport, "fs", moves the same bytes through files of a shared directory — the reference's own medium — for jobs
 // without RCCL and for the CPU tests (world 2, no GPU): same packing, same ordering, same code above the transport.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -40,12 +41,50 @@ struct Rccl {
     std::string error;
 };
 
+// Which RCCL.  A process may already carry one (PyTorch ships its own copy, without a SONAME, next to its own copy of the HIP
+// runtime): asking the loader for "librccl.so.1" would then map a second RCCL beside it — two sets of globals and a double free
+// when the process exits (measured: tools/rccl_copies_check.py).  So an RCCL that is already mapped is preferred, provided it
+// is bound to the same HIP runtime as this library (its hipMalloc is ours): buffers of one runtime mean nothing to the other.
+int collect_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    const char* path = info->dlpi_name;
+    if (!path) return 0;
+    const char* base = strrchr(path, '/');
+    base = base ? base + 1 : path;
+    if (!strncmp(base, "librccl.so", 10)) static_cast<std::vector<std::string>*>(out)->push_back(path);
+    return 0;
+}
+
+bool same_hip_runtime(void* handle) {
+    void* theirs = dlsym(handle, "hipMalloc");
+    hipError_t (*ours)(void**, size_t) = &hipMalloc;
+    return theirs == reinterpret_cast<void*>(ours);
+}
+
 Rccl* rccl() {
     static Rccl r;
     if (r.handle || !r.error.empty()) return &r;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
+    std::vector<std::string> candidates;
+    const char* forced = getenv("TZ_RCCL_LIB");   // an explicit library, e.g. /opt/rocm/lib/librccl.so.1
+    if (forced && *forced) candidates.push_back(forced);
+    else dl_iterate_phdr(collect_loaded_rccl, &candidates);
+    const bool had_loaded = !candidates.empty();
+    if (!(forced && *forced))
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) candidates.push_back(name);
+    std::string rejected;
+    for (const std::string& name : candidates) {
+        void* h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        if (same_hip_runtime(h)) {
+            r.handle = h;
+            break;
+        }
+        rejected += " " + name;
+        dlclose(h);
+    }
+    if (!r.handle && !rejected.empty()) {
+        r.error = "no RCCL bound to this library's HIP runtime (tried:" + rejected + "): the process holds two HIP runtimes" +
+                  (had_loaded ? " - import torch before takzero_amd, or" : ";") + " set TZ_RCCL_LIB";
+        return &r;
     }
     if (!r.handle) {
         r.error = std::string("cannot open librccl: ") + dlerror();

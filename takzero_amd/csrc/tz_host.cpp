@@ -71,13 +71,30 @@ struct MoveRecord {  // IncompleteTarget for every game of the shard at one move
     int width = 0;
 };
 
-// total order of Eval as one double (eval.rs:138-163): Loss(p) < values / draws < Win(p)
-double eval_key(uint8_t tag, uint32_t bits) {
-    switch (tag) {
-        case TZ_EVAL_LOSS: return -1e9 + (double)bits;
-        case TZ_EVAL_WIN: return 1e9 - (double)bits;
-        case TZ_EVAL_DRAW: return (double)(-0.05f) - (double)bits * 1e-12;
-        default: return (double)tz_bits_to_float(bits);
+// impl Ord for Eval (eval.rs:138-163) on (tag, bits) pairs as the ABI hands them over: Loss(a) < Loss(b) iff a < b; any Loss <
+// any Value / Draw < any Win; Win(a) < Win(b) iff a > b; a Draw compares with a Value as CONTEMPT = -0.05 does (and is Equal
+// to a Value of exactly -0.05); Draw(a) < Draw(b) iff a > b.
+int eval_cmp(uint8_t ta, uint32_t ba, uint8_t tb, uint32_t bb) {
+    constexpr float CONTEMPT = -0.05f;   // eval.rs:128
+    auto cmpf = [](float a, float b) { return a < b ? -1 : a > b ? 1 : 0; };
+    auto cmpu = [](uint32_t a, uint32_t b) { return a < b ? -1 : a > b ? 1 : 0; };
+    switch (ta) {
+        case TZ_EVAL_LOSS: return tb == TZ_EVAL_LOSS ? cmpu(ba, bb) : -1;
+        case TZ_EVAL_WIN: return tb == TZ_EVAL_WIN ? cmpu(bb, ba) : 1;
+        case TZ_EVAL_DRAW:
+            switch (tb) {
+                case TZ_EVAL_LOSS: return 1;
+                case TZ_EVAL_WIN: return -1;
+                case TZ_EVAL_DRAW: return cmpu(bb, ba);
+                default: return cmpf(CONTEMPT, tz_bits_to_float(bb));
+            }
+        default:
+            switch (tb) {
+                case TZ_EVAL_LOSS: return 1;
+                case TZ_EVAL_WIN: return -1;
+                case TZ_EVAL_DRAW: return cmpf(tz_bits_to_float(ba), CONTEMPT);
+                default: return cmpf(tz_bits_to_float(ba), tz_bits_to_float(bb));
+            }
     }
 }
 
@@ -127,6 +144,10 @@ struct tz_selfplay {
     HostExchange xch;
     std::vector<unsigned char> records;
     uint64_t n_gathered = 0;
+    // tests: observer of the decisions (tz_host_exchange.h HostTrace) and what it is shown
+    const HostTrace* trace = nullptr;
+    std::vector<double> draws;
+    std::vector<uint16_t> halving;
 };
 
 namespace {
@@ -208,28 +229,25 @@ int select_actions_in_selfplay(tz_selfplay* sp, std::vector<uint16_t>& out) {
         const int nc = (int)ri.n_children;
         if (ri.ply >= WEIGHTED_RANDOM_PLIES || ri.eval_tag != TZ_EVAL_VALUE || nc == 0) continue;
         const size_t o = (size_t)g * w;
-        int bi = 0;
-        double best_key = eval_key(sp->c_tag[o], sp->c_bits[o]);
-        for (int i = 1; i < nc; i++) {
-            const double key = eval_key(sp->c_tag[o + i], sp->c_bits[o + i]);
-            if (key < best_key) {
-                best_key = key;
-                bi = i;
-            }
-        }
+        int bi = 0;   // best_eval = the first minimum of the children's evaluations (Iterator::min)
+        for (int i = 1; i < nc; i++)
+            if (eval_cmp(sp->c_tag[o + i], sp->c_bits[o + i], sp->c_tag[o + bi], sp->c_bits[o + bi]) < 0) bi = i;
         // best_eval.map(|x| x + allowed_eval_drop): only a Value moves
-        const double limit = sp->c_tag[o + bi] == TZ_EVAL_VALUE
-                                 ? (double)(tz_bits_to_float(sp->c_bits[o + bi]) + ALLOWED_EVAL_DROP)
-                                 : best_key;
+        const uint8_t limit_tag = sp->c_tag[o + bi];
+        const uint32_t limit_bits = limit_tag == TZ_EVAL_VALUE ? tz_float_to_bits(tz_bits_to_float(sp->c_bits[o + bi]) + ALLOWED_EVAL_DROP)
+                                                               : sp->c_bits[o + bi];
         double total = 0.0;
         for (int i = 0; i < nc; i++) {
             const bool ok = sp->c_visits[o + i] >= SAMPLE_THRESHOLD && sp->c_tag[o + i] != TZ_EVAL_WIN &&
-                            eval_key(sp->c_tag[o + i], sp->c_bits[o + i]) <= limit;
+                            eval_cmp(sp->c_tag[o + i], sp->c_bits[o + i], limit_tag, limit_bits) <= 0;
             weight[i] = ok ? (double)sp->c_visits[o + i] : 0.0;
             total += weight[i];
         }
         if (total <= 0.0) continue;  // WeightError::InsufficientNonZero -> select_best_action
-        const double u = uni(sp->rng) * total;
+        const double u01 = uni(sp->rng);
+        if (sp->trace) sp->draws[g] = u01;
+        // rand's WeightedIndex over the u32 weights: an integer drawn uniformly from [0, total), first cumulative weight above it
+        const double u = std::floor(u01 * total);
         double acc = 0.0;
         int pick = nc - 1;
         for (int i = 0; i < nc; i++) {
@@ -478,6 +496,10 @@ int tz_selfplay_play_move(tz_selfplay* sp) {
     if (!sp) return tz_fail(TZ_EINVAL, "tz_selfplay_play_move: null handle");
     const int B = sp->B;
     int rc, w = 0;
+    if (sp->trace) {
+        sp->draws.assign(B, std::nan(""));
+        sp->halving.assign(B, 0xFFFF);
+    }
     if (sp->kind == 0) {
         if ((rc = TZS(simulate)(sp->search, sp->betas.data(), 1))) return rc;            // :128
         if ((rc = TZS(root_info)(sp->search, sp->info.data()))) return rc;
@@ -506,6 +528,7 @@ int tz_selfplay_play_move(tz_selfplay* sp) {
         }
         if ((rc = TZS(gumbel_sh)(sp->search, sp->betas.data(), sp->k, sp->sims, sp->gumbel.data(), sp->amax, sp->actions.data())))
             return rc;                                                                           // :138-144
+        if (sp->trace) sp->halving = sp->actions;
         if ((rc = TZS(root_info)(sp->search, sp->info.data()))) return rc;
         bool early = false;
         for (int g = 0; g < B; g++) early = early || sp->info[g].ply < WEIGHTED_RANDOM_PLIES;
@@ -518,12 +541,15 @@ int tz_selfplay_play_move(tz_selfplay* sp) {
                 if (ply[g] < WEIGHTED_RANDOM_PLIES) sp->actions[g] = sampled[g];
         }
     }
+    if (sp->trace && sp->trace->chosen) sp->trace->chosen(sp->draws, sp->halving, sp->actions);
     if ((rc = record(sp))) return rc;
     if ((rc = TZS(step)(sp->search, sp->actions.data()))) return rc;                        // take_a_step
     std::uniform_int_distribution<int> open(0, 15);
     for (int g = 0; g < B; g++) sp->choice[g] = open(sp->rng);
     if ((rc = TZS(restart_terminal)(sp->search, sp->choice.data(), sp->term.data()))) return rc;
     if ((rc = complete(sp))) return rc;
+    if (sp->trace && sp->trace->completed)
+        sp->trace->completed(sp->term, sp->t_states, sp->t_moves, sp->t_pol, sp->t_n, sp->t_value, sp->t_ube, sp->amax);
     sp->moves_played++;
     sp->positions += (uint64_t)B;
     return TZ_OK;
@@ -700,7 +726,12 @@ struct tz_reanalyze {
     uint64_t offset = 0, line_no = 0;
     std::string targets_text;
     uint64_t n_targets = 0;
+    const HostTrace* trace = nullptr;   // tests: observer of the targets (tz_host_exchange.h)
 };
+
+// tests only (not in the C ABI): observers of the two drivers' decisions
+void tz_selfplay_set_trace(tz_selfplay* sp, const HostTrace* t) { sp->trace = t; }
+void tz_reanalyze_set_trace(tz_reanalyze* ra, const HostTrace* t) { ra->trace = t; }
 
 namespace {
 
@@ -921,17 +952,23 @@ int tz_reanalyze_iterate(tz_reanalyze* ra) {
         memcpy(&pol_pad[(size_t)g * ra->amax], &pol[(size_t)g * w], sizeof(float) * nc);
         if (info[g].eval_tag != TZ_EVAL_VALUE) {  // solved root: its own evaluation (:184-187)
             value[g] = eval_to_f32(info[g].eval_tag, info[g].eval.ply);
-        } else {                                   // minus the selected child's evaluation (:188-195)
-            float v = 0.0f;
-            for (int i = 0; i < nc; i++)
+        } else {                                   // the selected child's evaluation, negated, then converted (:188-195):
+            float v = 0.0f;                        // Eval::negate flips a proven result AND adds a ply (eval.rs:40-47) before
+            for (int i = 0; i < nc; i++)           // f32::from discounts it, so Win(p) of the child gives -0.997^(p+1)
                 if (moves[(size_t)g * w + i] == selected[g]) {
                     const size_t o = (size_t)g * w + i;
-                    v = tag[o] == TZ_EVAL_VALUE ? tz_bits_to_float(bits[o]) : eval_to_f32(tag[o], bits[o]);
+                    if (tag[o] == TZ_EVAL_VALUE) {
+                        v = -tz_bits_to_float(bits[o]);
+                    } else {
+                        const uint8_t flipped = tag[o] == TZ_EVAL_WIN ? TZ_EVAL_LOSS : tag[o] == TZ_EVAL_LOSS ? TZ_EVAL_WIN : TZ_EVAL_DRAW;
+                        v = eval_to_f32(flipped, bits[o] + 1);
+                    }
                     break;
                 }
-            value[g] = -v;
+            value[g] = v;
         }
     }
+    if (ra->trace && ra->trace->reanalyzed) ra->trace->reanalyzed(selected, mv_pad, pol_pad, nm, value, ube, ra->amax);
     std::vector<char> out((size_t)B * 200 + total_moves * 40);
     uint64_t written = 0;
     if ((rc = tz_format_targets(ra->n, B, states.data(), mv_pad.data(), pol_pad.data(), nm.data(), ra->amax, value.data(), ube.data(),

@@ -119,9 +119,14 @@ class Reanalyze:
             nc = int(info["n_children"][g])
             if info["eval_tag"][g] != api.EVAL_VALUE:   # solved root: its own evaluation (:184-187)
                 value = api.eval_to_f32(info["eval_tag"][g], info["eval_bits"][g])
-            else:                                       # else minus the selected child's evaluation (:188-195)
+            else:                                       # else the selected child's evaluation, negated, then converted (:188-195):
                 j = int(np.nonzero(ch["move_idx"][g, :nc] == selected[g])[0][0])
-                value = -api.eval_to_f32(ch["eval_tag"][g, j], ch["eval_bits"][g, j])
+                tag, bits = int(ch["eval_tag"][g, j]), ch["eval_bits"][g, j]
+                if tag == api.EVAL_VALUE:
+                    value = -api.eval_to_f32(tag, bits)
+                else:                                   # Eval::negate flips a proven result and adds a ply (eval.rs:40-47)
+                    flipped = {api.EVAL_WIN: api.EVAL_LOSS, api.EVAL_LOSS: api.EVAL_WIN, api.EVAL_DRAW: api.EVAL_DRAW}[tag]
+                    value = api.eval_to_f32(flipped, int(bits) + 1)
             targets.append((states[g], ch["move_idx"][g, :nc].copy(), pol[g, :nc].copy(), float(value), float(ube[g])))
         return targets
 

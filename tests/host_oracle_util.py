@@ -41,5 +41,8 @@ def run(exe, prefix, n, half_komi, agent, batch, kind, sims, k, exploration, mov
     for part in parts or ("targets", "replays", "exploration", "reanalyze", "consumers"):
         with open("%s.%s" % (prefix, part), "rb") as f:
             out[part] = f.read()
-    out["positions"] = int(r.stdout.split()[1])
+    fields = dict(zip(r.stdout.split()[::2], r.stdout.split()[1::2]))
+    out["positions"] = int(fields["positions"])
+    for key in ("host_checks", "host_mismatches", "sampled_games", "proven_selected_children"):
+        out[key] = int(fields.get(key, -1))
     return out

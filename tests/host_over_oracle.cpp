@@ -41,6 +41,19 @@ int tzo_search_gumbel_sh(tzo_search* s, const float* betas, int sampled_actions,
                          uint16_t* selected_out);
 }
 
+// the oracle's restatement of the decisions above the search (oracle/host.hpp through oracle/capi.cpp)
+struct tzo_host;
+extern "C" {
+tzo_host* tzo_host_create(tzo_search* s);
+void tzo_host_destroy(tzo_host* h);
+int tzo_host_choose_and_record(tzo_host* h, int kind, const uint16_t* halving, const double* draws, float visitations, uint16_t* expected_out,
+                               uint8_t* sampled_out);
+int tzo_host_complete(tzo_host* h, const int8_t* terminal, const float* betas);
+int tzo_host_target(tzo_host* h, int i, tz_state* state_out, int amax, uint16_t* moves_out, float* policy_out, float* value_out, float* ube_out);
+int tzo_host_reanalyze_target(tzo_search* s, int g, uint16_t selected, int amax, uint16_t* moves_out, float* policy_out, float* value_out,
+                              float* ube_out);
+}
+
 #define TZS(name) tzo_search_##name
 #define TZ_SEARCH_T tzo_search
 // the two constructors take the search handle: give this build's versions names of their own
@@ -99,6 +112,56 @@ int main(int argc, char** argv) {
             return 11;
         }
     }
+    // Every decision the native driver takes above the search is checked, move by move, against the oracle's restatement of
+    // the reference's code (oracle/host.hpp), which looks at the same trees through its own Node / Eval objects and is handed
+    // the very draws the driver consumed: chosen actions (node/mod.rs:170-207, selfplay/src/main.rs:138-153), which games
+    // consumed a draw, and every completed target - position, policy, value, UBE, order (selfplay/src/main.rs:238-329).
+    unsigned long long checks = 0, mismatches = 0, sampled_games = 0;
+    tzo_host* host = kind == 2 ? nullptr : tzo_host_create(s);
+    HostTrace trace;
+    auto bits_equal = [](float a, float b) { return memcmp(&a, &b, 4) == 0; };
+    if (host) {
+        int lg = 0;
+        while ((1 << (lg + 1)) <= k) lg++;
+        const float visitations = lg > 0 ? (float)((sims / lg / k) * ((1 << lg) - 1)) : 0.0f;   // IMPROVED_POLICY_VISITATIONS, selfplay/src/main.rs:47-52
+        trace.chosen = [&, visitations](const std::vector<double>& draws, const std::vector<uint16_t>& halving, const std::vector<uint16_t>& actions) {
+            std::vector<uint16_t> expected(B);
+            std::vector<uint8_t> sampled(B);
+            std::vector<double> d(draws);
+            for (auto& x : d)
+                if (x != x) x = 0.0;
+            tzo_host_choose_and_record(host, kind, halving.data(), d.data(), visitations, expected.data(), sampled.data());
+            for (int g = 0; g < B; g++) {
+                if (expected[g] == 0xFFFF) continue;
+                checks += 2;
+                mismatches += expected[g] != actions[g];
+                mismatches += (sampled[g] != 0) != (draws[g] == draws[g]);   // the driver consumed a draw iff the reference would
+                sampled_games += sampled[g] != 0;
+            }
+        };
+        trace.completed = [&](const std::vector<int8_t>& terminal, const std::vector<tz_state>& states, const std::vector<uint16_t>& mv,
+                              const std::vector<float>& pol, const std::vector<int32_t>& count, const std::vector<float>& value,
+                              const std::vector<float>& ube, int amax) {
+            const int T = tzo_host_complete(host, terminal.data(), sp->betas.data());
+            checks++;
+            if (T != (int)count.size()) {
+                mismatches++;
+                return;
+            }
+            std::vector<uint16_t> emv(amax);
+            std::vector<float> epol(amax);
+            for (int i = 0; i < T; i++) {
+                tz_state st;
+                float v = 0, u = 0;
+                const int c = tzo_host_target(host, i, &st, amax, emv.data(), epol.data(), &v, &u);
+                checks++;
+                bool same = c == count[i] && !memcmp(&st, &states[i], sizeof st) && bits_equal(v, value[i]) && bits_equal(u, ube[i]);
+                for (int j = 0; same && j < c; j++) same = emv[j] == mv[(size_t)i * amax + j] && bits_equal(epol[j], pol[(size_t)i * amax + j]);
+                mismatches += !same;
+            }
+        };
+        tz_selfplay_set_trace(sp, &trace);
+    }
     std::string targets, replays, expl;
     for (int m = 0; m < moves; m++) {
         if (tz_selfplay_play_move(sp) || tz_selfplay_exchange(sp)) {
@@ -121,6 +184,7 @@ int main(int argc, char** argv) {
     dump(prefix + ".replays", replays);
     dump(prefix + ".exploration", expl);
     tz_selfplay_destroy(sp);
+    if (host) tzo_host_destroy(host);
     if (comm) {
         uint64_t collectives = 0, bytes = 0;
         tz_comm_info(comm, nullptr, nullptr, nullptr, &collectives, &bytes);
@@ -134,6 +198,30 @@ int main(int argc, char** argv) {
     if (tz_reanalyze_create(s, kind == 1 ? sims : 32, seed + 1, 0, 1, kind == 1 ? 1 : 0, k, &ra)) return 5;
     uint64_t added = 0, total = 0;
     if (tz_reanalyze_feed(ra, (prefix + ".replays").c_str(), &added, &total)) return 6;
+    HostTrace rtrace;   // reanalyze targets against reanalyze/src/main.rs:184-203 as the oracle restates it
+    unsigned long long proven_children = 0;
+    rtrace.reanalyzed = [&](const std::vector<uint16_t>& selected, const std::vector<uint16_t>& mv, const std::vector<float>& pol,
+                            const std::vector<int32_t>& count, const std::vector<float>& value, const std::vector<float>& ube, int amax) {
+        std::vector<uint16_t> emv(amax);
+        std::vector<float> epol(amax);
+        std::vector<tz_root_info> info(B);
+        tzo_search_root_info(s, info.data());
+        std::vector<uint8_t> tag((size_t)B * amax);
+        std::vector<uint16_t> cm((size_t)B * amax);
+        tzo_search_root_children(s, amax, cm.data(), nullptr, tag.data(), nullptr, nullptr, nullptr, nullptr);
+        for (int g = 0; g < B; g++) {
+            float v = 0, u = 0;
+            const int c = tzo_host_reanalyze_target(s, g, selected[g], amax, emv.data(), epol.data(), &v, &u);
+            checks++;
+            bool same = c == count[g] && bits_equal(v, value[g]) && bits_equal(u, ube[g]);
+            for (int j = 0; same && j < c; j++) same = emv[j] == mv[(size_t)g * amax + j] && bits_equal(epol[j], pol[(size_t)g * amax + j]);
+            mismatches += !same;
+            if (info[g].eval_tag == TZ_EVAL_VALUE)   // the case ADVICE r1 flagged: the selected child of an unsolved root is proven
+                for (int j = 0; j < c; j++)
+                    if (cm[(size_t)g * amax + j] == selected[g] && tag[(size_t)g * amax + j] != TZ_EVAL_VALUE) proven_children++;
+        }
+    };
+    tz_reanalyze_set_trace(ra, &rtrace);
     std::string re;
     if (total >= (uint64_t)B) {
         for (int it = 0; it < 2; it++) {
@@ -145,7 +233,8 @@ int main(int argc, char** argv) {
         re = ra->targets_text;
     }
     dump(prefix + ".reanalyze", re);
-    printf("positions %llu\n", (unsigned long long)total);
+    printf("positions %llu host_checks %llu host_mismatches %llu sampled_games %llu proven_selected_children %llu\n", (unsigned long long)total, checks,
+           mismatches, sampled_games, proven_children);
     tz_reanalyze_destroy(ra);
     // evaluation::compete and the puzzle benchmark on the 16 openings (game g starts from opening g % 16)
     {

@@ -9,34 +9,32 @@ from gpu_util import require_gpu
 pytestmark = pytest.mark.gpu
 
 
+def test_rccl_communicator_in_clean_processes():
+    """Which RCCL the library opens (csrc/tz_comm.cpp rccl()): alone in the process the system's librccl.so.1; after
+    `import torch` (bench.py's order under torchrun) PyTorch's own copy, so that one RCCL and one HIP runtime serve both."""
+    import os
+    import subprocess
+    import sys
+
+    require_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for order, lib in (("none", "/opt/rocm"), ("torch_first", "torch/lib/librccl.so")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_copies_check.py"), order], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (order, r.stdout[-500:], r.stderr[-1500:])
+        maps = [ln for ln in r.stdout.splitlines() if ln.startswith(order)]
+        assert len(maps) == 1 and maps[0].count("librccl") == 1 and lib in maps[0], r.stdout
+        assert "[b'abc']" in r.stdout and "'transport': 'rccl'" in r.stdout
+
+
 def test_rccl_communicator_of_one_rank(tmp_path):
-    A = require_gpu()
-    from takzero_amd import comm as CM
-    from takzero_amd import weights as W
+    """ncclCommInitRank / ncclAllGather / ncclBroadcast at world 1, the model hand-over and the self-play driver on top of
+    them: in a process of its own (tests/comm_world1_script.py) that imports torch first, as bench.py does under torchrun — this
+    pytest process has loaded the library before torch and would end up with two RCCL copies (see tools/rccl_copies_check.py)."""
+    import os
+    import subprocess
+    import sys
 
-    c = CM.Comm.rccl(CM.unique_id(), 0, 1, 0)
-    assert c.info()["transport"] == "rccl" and c.info()["world"] == 1
-    blob = bytes(np.random.default_rng(0).integers(0, 256, 100_003, dtype=np.uint8))
-    assert c.all_gather(blob) == [blob] and c.all_gather(b"") == [b""]
-    assert c.broadcast(blob) == blob
-    c.barrier()
-    assert c.info()["collectives"] == 2 and c.info()["bytes_gathered"] == len(blob)
-    # Net::load handed over (status 0 = the root has a new model): a no-op for the root itself, and the driver keeps playing
-    net = A.Net(arch=A.ARCH_TEST, n=4, blocks=1).load_tensors(W.init_weights(W.ARCH_TEST, n=4, blocks=1, seed=1))
-    c.broadcast_net(net, 0, 0)
-    c.broadcast_net(net, 0, 1)
-    from takzero_amd.selfplay import NativeSelfPlay
-
-    mcts = A.BatchedMCTS(8, 4, 4, agent=net, node_capacity=1 << 12)
-    sp = NativeSelfPlay(mcts, 8, seed=1, search="puct")
-    sp.set_comm(c, 0)
-    for _ in range(30):
-        sp.play_move()
-        sp.exchange()
-    assert sp.take_text(1).count(b"\n") == sp.counters()["replays"]
-    sp.close()
-    c.close()
-    # the id can also travel through a directory (what examples/selfplay_cli.cpp --comm rccl does)
-    c2 = CM.Comm.rccl_from_directory(tmp_path, 0, 1, 0)
-    assert (tmp_path / "rccl_id.bin").stat().st_size == CM.ID_BYTES and c2.all_gather(b"xy") == [b"xy"]
-    c2.close()
+    require_gpu()
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "comm_world1_script.py"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "COMM-WORLD1-OK" in r.stdout, (r.stdout[-800:], r.stderr[-2000:])

@@ -273,8 +273,9 @@ def test_simhash_net_saves_and_loads_its_set_beside_the_model(oracle, tmp_path):
     A = require_gpu()
 
     a = A.Net.new(arch=A.ARCH_NET4_SIMHASH, seed=2)
-    states = O.states_array(random_positions(oracle, O, 4, 4, 16, 5, max_ply=20))
-    acts = [O.possible_moves(oracle, s) for s in states]
+    positions = random_positions(oracle, O, 4, 4, 16, 5, max_ply=20)
+    states = O.states_array(positions)
+    acts = [O.possible_moves(oracle, s) for s in positions]
     a.hash_indices(states[:8], update=True)
     var = a.policy_value_uncertainty(states, acts)[2]
     assert np.any(var < 4.0) and np.any(var == 4.0)
