@@ -62,14 +62,15 @@ def rnd(w, planes):
         return ((raw - mn) / (mx - mn)).clamp(0.0, 1.0) * MAXIMUM_VARIANCE
 
 
-def simhash_indices(w, planes, cin):
-    """get_indices, net6_simhash.rs:202-236."""
+def simhash_indices(w, planes, cin, return_dots=False):
+    """get_indices, net6_simhash.rs:202-236 (with return_dots also the 32 projections whose signs are the bits)."""
     x = torch.from_numpy(planes.copy())
     with torch.no_grad():
         x[:, cin - 2] = 0.0
         dots = x.reshape(x.shape[0], -1) @ _t(w, "simhash_matrix")
         bits = (~(dots < 0.0)).to(torch.int64)
-        return (bits * (2 ** torch.arange(32, dtype=torch.int64))).sum(dim=1).numpy()
+        idx = (bits * (2 ** torch.arange(32, dtype=torch.int64))).sum(dim=1).numpy()
+        return (idx, dots.numpy()) if return_dots else idx
 
 
 def variance(w, planes, ube, arch, seen=None):

@@ -31,8 +31,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, ablations=None):
+    """ablations (or TZ_BUILD_ABLATIONS=1): also compile the A/B twins and ablation variants of the network kernels that
+    tz_debug_conv_bench / tz_debug_tower_bench time (tools/tower_bench.py, tools/conv_bench.py); the shipped object has none."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if ablations is None:
+        ablations = os.environ.get("TZ_BUILD_ABLATIONS", "0") not in ("", "0")
+    stamp = os.path.join(CSRC, ".ablations")
+    if ablations != os.path.exists(stamp):        # switching the flavour rebuilds the network unit
+        force_nn = True
+        if ablations:
+            open(stamp, "w").close()
+        elif os.path.exists(stamp):
+            os.remove(stamp)
+    else:
+        force_nn = False
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "takzero_hip.h"))
     objs = []
@@ -41,8 +54,8 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", s, "-o", o]
+        if force or _stale(o, [s] + headers) or (force_nn and src == "tz_nn.hip"):
+            cmd = [hipcc] + COMMON + extra + (["-DTZ_ABLATIONS"] if ablations and src == "tz_nn.hip" else []) + ["-x", "hip", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -63,4 +76,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablations=True if "--ablations" in sys.argv else None))

@@ -715,6 +715,7 @@ __global__ __launch_bounds__(512, 2) void tower_mfma_kernel(TowerArgs a) {
 // LDS feeds 4 MFMAs instead of 2 (half the ds_read bytes) at 28 accumulator tiles per wave; the two waves of a channel
 // group fetch the same weight fragments (the second fetch comes from the vector L1).  Waves w and w+4 share a SIMD and
 // are one wave of each half, so the SIMD's MFMA count per k-step is unchanged.
+#ifdef TZ_ABLATIONS   // the 4 channel groups x 2 row halves twin of the tower (measured 3 % slower): diagnostic builds only
 template <int NB, int P, int RTW, typename ET>
 __device__ __forceinline__ void tower4x2_body(const TowerArgs& a, unsigned char* lds, const int* tap_table, int lane, int cg, int tile0,
                                               int valid_rows, size_t m0) {
@@ -877,6 +878,8 @@ __global__ __launch_bounds__(512, 2) void tower4x2_mfma_kernel(TowerArgs a) {
     if (wave < 4) tower4x2_body<NB, P, RT_A, ET>(a, lds, tap_table, lane, wave, 0, valid_rows, m0);
     else tower4x2_body<NB, P, RT_B, ET>(a, lds, tap_table, lane, wave - 4, RT_A, valid_rows, m0);
 }
+
+#endif  // TZ_ABLATIONS
 
 // ---------------------------------------------------------------------------------------------
 // The whole trunk and its heads in ONE launch: game_repr + first conv (net5.rs:46-64), the residual tower, the policy
@@ -2358,6 +2361,7 @@ int conv_bf16(tz_net* net, const ConvW& L, const void* in, const tz_state* state
     return conv_dispatch<__bf16>(net->n, board, a, L.cout_pad, in == nullptr, max_positions, st);
 }
 
+#ifdef TZ_ABLATIONS
 template <int NB>
 int launch_tower4x2(const TowerArgs& a, int max_positions, hipStream_t st) {
     constexpr int P = ppt_for(NB), NN = NB * NB, RT = (P * NN + 15) / 16, LROWS = RT * 16 + 8;
@@ -2376,6 +2380,7 @@ int launch_tower4x2(const TowerArgs& a, int max_positions, hipStream_t st) {
     if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("tower4x2 launch: ") + hipGetErrorString(e));
     return TZ_OK;
 }
+#endif  // TZ_ABLATIONS
 
 template <int NB, int OPT = 0, typename ET = __bf16>
 int launch_tower(const TowerArgs& a, int max_positions, hipStream_t st) {
@@ -3175,6 +3180,7 @@ int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, floa
         for (int i = 0; i < n && !rc; i++) {
             switch (variant) {
                 case 0: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 0>(a, positions, 1, net->stream); break;
+#ifdef TZ_ABLATIONS   // diagnostic builds only (python -m takzero_amd.build --ablations): the A/B twins stay out of the shipped object
                 case 1: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 1>(a, positions, 1, net->stream); break;
                 case 2: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 2>(a, positions, 1, net->stream); break;
                 case 3: rc = launch_conv<5, ppt_for(5), 8, 2, 9, false, true, 3>(a, positions, 1, net->stream); break;
@@ -3190,7 +3196,8 @@ int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, floa
                 case 12: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 2>(a, positions, 1, net->stream); break;
                 case 13: rc = launch_conv<5, ppt_small(5), 4, 4, 9, false, true, 3>(a, positions, 1, net->stream); break;
                 case 14: rc = launch_conv<5, ppt_small(5), 4, 4, 1, false, true, 0>(a, positions, 1, net->stream); break;
-                default: rc = tz_fail(TZ_EINVAL, "tz_debug_conv_bench: unknown variant");
+#endif
+                default: rc = tz_fail(TZ_EINVAL, "tz_debug_conv_bench: unknown variant (the ablation variants need a build with --ablations)");
             }
         }
         return rc;
@@ -3240,6 +3247,8 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
         int r = TZ_OK;
         for (int i = 0; i < n && !r; i++) {
             switch (variant) {
+                case 4224: r = launch_tower<5, 4224>(a, positions, net->stream); break;  // 4096 + 128 = the shipped loop (TZ_TOWER=1)
+#ifdef TZ_ABLATIONS   // diagnostic builds only (python -m takzero_amd.build --ablations)
                 case 0: r = launch_tower<5, 0>(a, positions, net->stream); break;
                 case 1: r = launch_tower<5, 1>(a, positions, net->stream); break;
                 case 2: r = launch_tower<5, 2>(a, positions, net->stream); break;
@@ -3255,7 +3264,6 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 512: r = launch_tower<5, 512>(a, positions, net->stream); break;
                 case 1024: r = launch_tower<5, 1024>(a, positions, net->stream); break;
                 case 2048: r = launch_tower<5, 2048>(a, positions, net->stream); break;
-                case 4224: r = launch_tower<5, 4224>(a, positions, net->stream); break;  // 4096 + 128 = the shipped loop
                 case 4240: r = launch_tower<5, 4240>(a, positions, net->stream); break;  // ... without activation reads
                 case 4256: r = launch_tower<5, 4256>(a, positions, net->stream); break;  // ... without the weight stream
                 case 4272: r = launch_tower<5, 4272>(a, positions, net->stream); break;  // ... without both
@@ -3269,7 +3277,8 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
                 case 20608: r = launch_tower<5, 20608>(a, positions, net->stream); break;   // shipped loop, weight loads sc0
                 case 36992: r = launch_tower<5, 36992>(a, positions, net->stream); break;   // ... sc1
                 case 69760: r = launch_tower<5, 69760>(a, positions, net->stream); break;   // ... nt
-                default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant");
+#endif
+                default: r = tz_fail(TZ_EINVAL, "tz_debug_tower_bench: unknown variant (the ablation variants need a build with --ablations)");
             }
         }
         return r;

@@ -195,9 +195,14 @@ def test_simhash_indices_counts_and_bitvec_file(oracle, tmp_path):
     states = random_positions(oracle, O, 4, 4, 24, 5, max_ply=20)
     arr = O.states_array(states)
     planes = _planes(oracle, states).reshape(24, -1, 4, 4)
-    want = T.simhash_indices(w, planes, planes.shape[1]).astype(np.uint32)
+    want, dots = T.simhash_indices(w, planes, planes.shape[1], return_dots=True)
+    want = want.astype(np.uint32)
     got = net.hash_indices(arr)
-    assert (got == want).mean() > 0.9   # a dot product within rounding of zero may flip one of the 32 sign bits
+    # every bit is the sign of a 448-term fp32 dot product (net6_simhash.rs:224-233): a bit may differ from torch's only where
+    # that projection is within summation-order rounding of zero
+    differ = ((got[:, None] ^ want[:, None]) >> np.arange(32, dtype=np.uint32)[None, :]) & 1
+    assert np.all(np.abs(dots[differ == 1]) < 1e-4), (np.abs(dots[differ == 1]).max(), int(differ.sum()))
+    assert (got == want).mean() >= 0.9 and np.abs(dots).min() < 1.0
     acts = [O.possible_moves(oracle, s) for s in states]
     var0 = net.policy_value_uncertainty(arr, acts)[2]
     assert np.all(var0 == 4.0)           # nothing seen yet: maximum variance (net6_simhash.rs:246-255)
