@@ -411,6 +411,9 @@ int tz_device_math(int op, const float* a, const float* b, float* out, int n);
 int tz_debug_conv_bench(tz_net* net, int variant, int positions, int iters, float* ms_out);
 /* Diagnostic: the same for the fused residual-tower kernel (variant = its OPT bitmask). */
 int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, float* ms_out);
+/* Diagnostic (builds with --ablations, TZ_NET_ABL=8): in-kernel shader clock of the last stamped launch of the net kernel
+ * (median over workgroups of delta s_memtime / delta s_memrealtime x 100 MHz) and the median duration of its tower part. */
+int tz_debug_net_clock(tz_net* net, double* mhz_out, double* tower_us_out);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,8 @@ struct tz_net {
     void *rnd_in = nullptr, *rnd_h1 = nullptr, *rnd_h2 = nullptr;  // RND activations
     float* rnd_out = nullptr;                                       // [2][max_batch][512]
     hipStream_t stream = nullptr;
+    void* dbg_buf = nullptr;   // diagnostic builds: in-kernel stamps of the last launch (tz_debug_net_clock)
+    int dbg_groups = 0;
     // staging of the Agent surface (tz_net_eval): one pinned host buffer and one device buffer, grown on demand, so that
     // a call is one host-to-device copy, the kernels, one device-to-host copy
     void* eval_host = nullptr;

@@ -17,6 +17,7 @@
 #include "tz_nn.h"
 #include "tz_ot.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -911,6 +912,7 @@ struct NetArgs {
     const uint16_t* w_in_lo;
     const uint16_t* w_lo;
     const uint16_t* w_pol_lo;
+    unsigned long long* dbg;   // diagnostic builds (ABL & 8): [workgroup][4] = memtime, memrealtime before / after the tower
 };
 
 // 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
@@ -1114,7 +1116,9 @@ struct IntC {
 };
 
 // k_loop_256 with the tap loop unrolled and the all-zero (tap, row tile) pairs of the row map left out
-template <int NB, int P, int RNX, int PLANE, typename ET, typename WL>
+// ABL (diagnostic builds only, TZ_ABLATIONS): 1 = the activation fragments are read once and reused (no ds_read stream),
+// 2 = the weight fragments are fetched once and reused (no L2 stream), 4 = operands stream but no MFMA is issued.
+template <int NB, int P, int RNX, int PLANE, typename ET, int ABL = 0, typename WL>
 __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const int* tap_table, int lane,
                                                 f32x4 (&acc)[RowMap<NB, P, true>::RT][RNX], WL wl) {
     typedef typename Elem<ET>::x8 ex8;
@@ -1143,12 +1147,14 @@ __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const 
         constexpr unsigned NEXT = tap + 1 < TAPS ? RM::tap_tile_mask(tap + 1 < TAPS ? tap + 1 : tap) : 0u;
 #pragma unroll
         for (int kc = 0; kc < 8; kc++) {
-            if (kc + 2 < 8) {
+            if constexpr (!(ABL & 2)) {
+                if (kc + 2 < 8) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
-            } else if (tap + 1 < TAPS) {
+                    for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
+                } else if (tap + 1 < TAPS) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+                    for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kc == 7) {
@@ -1167,20 +1173,31 @@ __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const 
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 if ((NOW >> rt) & 1) {
+                    if constexpr (ABL & 4) {   // keep the operands live without issuing the MFMAs
 #pragma unroll
-                    for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], av[rt], acc[rt][j]);
+                        for (int j = 0; j < RNX; j++) asm volatile("" ::"v"(bq[kc & ((ABL & 2) ? 1 : 3)][j]), "v"(av[rt]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & ((ABL & 2) ? 1 : 3)][j], av[rt], acc[rt][j]);
+                    }
                 }
-                if (kc < 7) {
-                    if ((NOW >> rt) & 1) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
-                } else if ((NEXT >> rt) & 1) {
-                    av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                if constexpr (!(ABL & 1)) {
+                    if (kc < 7) {
+                        if ((NOW >> rt) & 1) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
+                    } else if ((NEXT >> rt) & 1) {
+                        av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+                    }
+                } else if (kc == 7 && tap == 0) {   // one refill per conv so that every tile holds a fragment
+                    if (((NEXT & ~NOW) >> rt) & 1) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
                 }
             }
             // the issue order of k_loop_256: the MFMAs of a row tile, then the ds_read that refills its fragment
+            if constexpr (ABL == 0) {
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                if ((NOW >> rt) & 1) __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
-                if (kc < 7 ? ((NOW >> rt) & 1) : ((NEXT >> rt) & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int rt = 0; rt < RT; rt++) {
+                    if ((NOW >> rt) & 1) __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
+                    if (kc < 7 ? ((NOW >> rt) & 1) : ((NEXT >> rt) & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
     };
@@ -1309,7 +1326,9 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 }
 
 // SP = 1: split precision (k_loop_split): 16 image planes (hi 0..7, lo 8..15), two accumulator sets, hi / lo weight buffers.
-template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0>
+// ABL: ablation bits of k_loop_256_skip for the tower (diagnostic builds); bit 8 = stamp s_memtime / s_memrealtime around the tower
+// into a.dbg (the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back item 6) - no output depends on the stamps.
+template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
@@ -1527,6 +1546,12 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     // ---- residual tower
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? a.w_lo : a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    if constexpr (ABL & 8) {
+        if (tid == 0 && a.dbg) {
+            a.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+            a.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
     for (int layer = 0; layer < a.nlayers; layer++) {
         if ((layer & 1) == 0) {
 #pragma unroll
@@ -1554,7 +1579,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
             };
-            if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET>(lds, tap_table, lane, acc, wl);
+            if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 7)>(lds, tap_table, lane, acc, wl);
             else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
         }
         __syncthreads();
@@ -1599,6 +1624,12 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         }
     }
     __syncthreads();  // the image now holds the tower's output
+    if constexpr (ABL & 8) {
+        if (tid == 0 && a.dbg) {
+            a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+            a.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
     // ---- value / UBE heads: conv1x1(256->1)+bias, ReLU over the image rows, then Linear(nn->1) per board
     {
         const float* hw = a.heads;
@@ -2431,12 +2462,12 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0>
+template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
     constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
     static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
-    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP>;
+    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
     int attr_dev = 0;
     TZ_HIP(hipGetDevice(&attr_dev));
@@ -2482,6 +2513,20 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
     if (net->n == 5 && small == 4) return launch_net<5, 1, ET, false, 4>(a, max_positions, st);
     if (net->n == 6 && small == 1) return launch_net<6, 2, ET, false, 1>(a, max_positions, st);
     if (net->n == 6 && small == 2) return launch_net<6, 2, ET, false, 2>(a, max_positions, st);
+#ifdef TZ_ABLATIONS   // TZ_NET_ABL=<bits>: the ablated twins of the shipped 5x5 kernel (tools/net_ablation.py)
+    if (const char* e = getenv("TZ_NET_ABL")) {
+        if (net->n == 5 && sq && small == 0 && sizeof(ET) == 2) {
+            switch (atoi(e)) {
+                case 1: return launch_net<5, 1, ET, true, 8, 0, 1>(a, max_positions, st);
+                case 2: return launch_net<5, 1, ET, true, 8, 0, 2>(a, max_positions, st);
+                case 3: return launch_net<5, 1, ET, true, 8, 0, 3>(a, max_positions, st);
+                case 4: return launch_net<5, 1, ET, true, 8, 0, 4>(a, max_positions, st);
+                case 8: return launch_net<5, 1, ET, true, 8, 0, 8>(a, max_positions, st);
+                default: break;
+            }
+        }
+    }
+#endif
     switch (net->n) {
         case 3: return sq ? launch_net<3, 1, ET, true>(a, max_positions, st) : launch_net<3, 1, ET, false>(a, max_positions, st);
         case 4: return launch_net<4, 1, ET, false>(a, max_positions, st);
@@ -2527,6 +2572,14 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.w_in_lo = net->conv_in.w_lo;
     a.w_lo = net->tower_w_lo;
     a.w_pol_lo = net->policy.w_lo;
+    a.dbg = nullptr;
+#ifdef TZ_ABLATIONS
+    if (getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 8) {
+        if (!net->dbg_buf) TZ_HIP(hipMalloc(&net->dbg_buf, (size_t)65536 * 4 * sizeof(unsigned long long)));
+        a.dbg = reinterpret_cast<unsigned long long*>(net->dbg_buf);
+        net->dbg_groups = (max_positions + 7) / 8;
+    }
+#endif
     if (net->precision == TZ_PREC_F16X2) {
         // split precision: hi and lo planes share the 160 KB, so half the boards per workgroup (5x5: 4 boards, square-major
         // rows, 14 of 63 (tap, tile) pairs skipped; the other sizes board-major)
@@ -3303,6 +3356,30 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
         }
         fprintf(stderr, "tower variant %d: output sum %llu hash %016llx\n", variant, sum, x);
     }
+    return TZ_OK;
+}
+
+// Diagnostic builds: the in-kernel shader clock of the last stamped launch (TZ_NET_ABL=8): median over workgroups of
+// delta s_memtime / delta s_memrealtime x 100 MHz, and the median tower duration in microseconds.
+int tz_debug_net_clock(tz_net* net, double* mhz_out, double* tower_us_out) {
+    if (!net || !net->dbg_buf || net->dbg_groups <= 0) return tz_fail(TZ_ESTATE, "tz_debug_net_clock: no stamped launch (build --ablations, TZ_NET_ABL=8)");
+    TZ_HIP(hipSetDevice(net->device));
+    TZ_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)net->dbg_groups * 4);
+    TZ_HIP(hipMemcpy(h.data(), net->dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> mhz, us;
+    for (int g = 0; g < net->dbg_groups; g++) {
+        const double dc = (double)(h[g * 4 + 2] - h[g * 4 + 0]), dr = (double)(h[g * 4 + 3] - h[g * 4 + 1]);
+        if (dr > 0) {
+            mhz.push_back(dc / dr * 100.0);
+            us.push_back(dr / 100.0);
+        }
+    }
+    if (mhz.empty()) return tz_fail(TZ_ESTATE, "tz_debug_net_clock: empty stamps");
+    std::sort(mhz.begin(), mhz.end());
+    std::sort(us.begin(), us.end());
+    if (mhz_out) *mhz_out = mhz[mhz.size() / 2];
+    if (tower_us_out) *tower_us_out = us[us.size() / 2];
     return TZ_OK;
 }
 

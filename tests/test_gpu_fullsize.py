@@ -112,7 +112,7 @@ def test_reanalyze_at_full_size_config5(oracle, tmp_path):
     big = A.BatchedMCTS(B, n, 4, agent=net)
     ra = RA.NativeReanalyze(big, sims, seed=3, rank=0, world=1, search="puct")
     total = ra.feed(rpath)
-    moves_in_file = sum(len(ln.split()) - 4 for ln in lines)   # [TPS "a b c"] m1 ... result: tokens minus tag (3) and result (1)
+    moves_in_file = sum(len(ln.split()) - 5 for ln in lines)   # [TPS "a b c"] m1 ... result: tokens minus the tag's 4 and the result
     assert total == moves_in_file and total >= MIN_POSITIONS, (total, moves_in_file)
     # 8 GPUs: replay line i belongs to rank i mod 8 - the eight buffers partition the single-rank one
     split = []
@@ -120,7 +120,7 @@ def test_reanalyze_at_full_size_config5(oracle, tmp_path):
     for r in range(8):
         rr = RA.NativeReanalyze(small_eng, 16, seed=3, rank=r, world=8, search="puct")
         split.append(rr.feed(rpath))
-        assert split[-1] == sum(len(ln.split()) - 4 for ln in lines[r::8])
+        assert split[-1] == sum(len(ln.split()) - 5 for ln in lines[r::8])
         rr.close()
     small_eng.close()
     assert sum(split) == total and min(split) > total // 10
@@ -161,7 +161,8 @@ def test_reanalyze_at_full_size_config5(oracle, tmp_path):
     for g in list(range(K)) + list(range(K, B, 97)):
         st, mv, pol, value, ube = targets[g]
         nc = int(bi["n_children"][g])
-        assert st.tobytes() == states[g].tobytes() and np.array_equal(mv, bc["move_idx"][g, :nc])
+        # (TPS does not carry reversible_plies, target.rs:322-326: compare the positions as text)
+        assert A.state_to_tps(st) == A.state_to_tps(states[g]) and np.array_equal(mv, bc["move_idx"][g, :nc])
         assert abs(float(np.sum(pol, dtype=np.float64)) - 1.0) < 1e-4 and -1.0 <= value <= 1.0 and 0.0 <= ube <= 4.0
         if bi["eval_tag"][g] == A.EVAL_VALUE:   # value = the selected (= best) child's evaluation, negated first (reanalyze/src/main.rs:188-195)
             j = int(np.nonzero(bc["move_idx"][g, :nc] == best[g])[0][0])
