@@ -1005,6 +1005,12 @@ struct RowMap {
             constexpr int T[25] = {1, 2, 3, 4, 5, 10, 15, 20, 21, 22, 23, 24, 9, 14, 19, 6, 7, 8, 11, 12, 13, 16, 17, 18, 0};
             return T[k];
         }
+        if (PERM && NB == 6 && P == 8) {  // pairs: bottom row, top row, left and right columns without corners (3 taps off the board
+                                          // for both squares of a pair), then the interior: 30 of the 162 (tap, tile) pairs skipped
+            constexpr int T[36] = {0, 1, 2, 3, 4, 5, 30, 31, 32, 33, 34, 35, 6, 12, 18, 24, 11, 17, 23, 29,
+                                   7, 8, 9, 10, 13, 14, 15, 16, 19, 20, 21, 22, 25, 26, 27, 28};
+            return T[k];
+        }
         if (PERM && NB == 6) {  // fours: the edges without corners, the corners, interior.  Inside a four the places alternate
                                 // with the checkerboard colour of the square ((x + y) & 1 == place & 1): the 16-B piece
                                 // rotation of the LDS image follows bit 2 of the row = bit 0 of the place, and any tap moves
@@ -1019,6 +1025,11 @@ struct RowMap {
     __host__ __device__ static constexpr int place_of(int square) {
         if (PERM && NB == 5) {
             constexpr int I[25] = {24, 0, 1, 2, 3, 4, 15, 16, 17, 12, 5, 18, 19, 20, 13, 6, 21, 22, 23, 14, 7, 8, 9, 10, 11};
+            return I[square];
+        }
+        if (PERM && NB == 6 && P == 8) {
+            constexpr int I[36] = {0, 1, 2, 3, 4, 5, 12, 20, 21, 22, 23, 16, 13, 24, 25, 26, 27, 17,
+                                   14, 28, 29, 30, 31, 18, 15, 32, 33, 34, 35, 19, 6, 7, 8, 9, 10, 11};
             return I[square];
         }
         if (PERM && NB == 6) {
@@ -1090,6 +1101,7 @@ static_assert(row_map_is_permutation<5, 8, true>() && row_map_is_permutation<6, 
               "RowMap: row_of / decode must be inverse bijections");
 static_assert(row_map_pairs_issued<5, 8, true>() == 91 && row_map_pairs_issued<5, 8, false>() == 117, "5x5: 26 of 117 pairs skipped");
 static_assert(row_map_pairs_issued<6, 4, true>() == 69 && row_map_pairs_issued<3, 16, true>() == 49, "6x6: 12 of 81, 3x3: 32 of 81");
+static_assert(row_map_is_permutation<6, 8, true>() && row_map_pairs_issued<6, 8, true>() == 132, "6x6 with 8 boards: 30 of 162 pairs skipped");
 
 // tap table entries of a lane under a row map (the general form of tap_bases_rc)
 template <int NB, int P, bool PERM, int LAYOUT>
@@ -1198,6 +1210,91 @@ __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const 
                     if ((NOW >> rt) & 1) __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
                     if (kc < 7 ? ((NOW >> rt) & 1) : ((NEXT >> rt) & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+            }
+        }
+    };
+    one_tap(IntC<0>{});
+    one_tap(IntC<1>{});
+    one_tap(IntC<2>{});
+    one_tap(IntC<3>{});
+    one_tap(IntC<4>{});
+    one_tap(IntC<5>{});
+    one_tap(IntC<6>{});
+    one_tap(IntC<7>{});
+    one_tap(IntC<8>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same conv for workgroups whose rows do not fit the register file of k_loop_256_skip: 6x6 with 8 boards is 18 row tiles,
+// 144 accumulator registers, and a whole k-step of activation fragments ahead (72 more) does not fit beside them.  Here the
+// fragments go through a ring of D registers that runs D (tap-tile, k-chunk) pairs ahead of the MFMAs, restarted at every tap;
+// the lane's fragment addresses come from the compact table  tap_c[tap][rt][slot] + lane_const  (all rows of a square's 8-row run
+// move together under a tap, so one entry per (tap, tile, square slot) is enough: 1.3 KB instead of 41 KB per-lane entries, which
+// is what lets 8 boards' image fit the 160 KB at all).  Same k order as the other loops: bit-identical results.
+template <int NB, int P, int RNX, int PLANE, typename ET, int D, typename WL>
+__device__ __forceinline__ void k_loop_256_ring(const unsigned char* lds, const int* tap_c, int slot, int lane_const,
+                                                f32x4 (&acc)[RowMap<NB, P, true>::RT][RNX], WL wl) {
+    typedef typename Elem<ET>::x8 ex8;
+    typedef RowMap<NB, P, true> RM;
+    constexpr int TAPS = 9, RT = RM::RT, PPT = RM::PPT;
+    ex8 bq[4][RNX];
+#pragma unroll
+    for (int j = 0; j < RNX; j++) {
+        bq[0][j] = wl(0, 0, j);
+        bq[1][j] = wl(0, 1, j);
+    }
+    auto one_tap = [&](auto tap_c_) {
+        constexpr int tap = decltype(tap_c_)::value;
+        constexpr unsigned NOW = RM::tap_tile_mask(tap);
+        constexpr int NA = __builtin_popcount(NOW), NP = 8 * NA;
+        // the rt of the i-th active tile of this tap
+        auto nth = [](int i) constexpr -> int {
+            int seen = 0;
+            for (int rt = 0; rt < RT; rt++)
+                if ((NOW >> rt) & 1) {
+                    if (seen == i) return rt;
+                    seen++;
+                }
+            return 0;
+        };
+        int abase[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            if ((NOW >> rt) & 1) abase[rt] = tap_c[(tap * RT + rt) * PPT + slot] + lane_const;
+        ex8 rg[D];
+#pragma unroll
+        for (int p = 0; p < D && p < NP; p++) rg[p] = *reinterpret_cast<const ex8*>(lds + abase[nth(p % NA)] + (p / NA) * PLANE);
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            if (kc + 2 < 8) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
+            } else if (tap + 1 < TAPS) {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const int p = kc * NA + i;          // this pair; its fragment sits in ring slot p % D
+                const int rt = nth(i);
+#pragma unroll
+                for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & 3][j], rg[p % D], acc[rt][j]);
+                const int pn = p + D;               // the pair D ahead refills the slot
+                if (pn < NP) {
+                    const int kn = pn / NA, rn = nth(pn % NA);
+                    if (pn % NA == 0 && kn == 4) {  // the read stream enters plane 4: rebase so that the offsets stay 16-bit immediates
+#pragma unroll
+                        for (int r2 = 0; r2 < RT; r2++)
+                            if ((NOW >> r2) & 1) {
+                                abase[r2] += 4 * PLANE;
+                                asm volatile("" : "+v"(abase[r2]));
+                            }
+                    }
+                    rg[p % D] = *reinterpret_cast<const ex8*>(lds + abase[rn] + (kn - (kn >= 4 ? 4 : 0)) * PLANE);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
+                if (pn < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
     };
@@ -1328,7 +1425,8 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 // SP = 1: split precision (k_loop_split): 16 image planes (hi 0..7, lo 8..15), two accumulator sets, hi / lo weight buffers.
 // ABL: ablation bits of k_loop_256_skip for the tower (diagnostic builds); bit 8 = stamp s_memtime / s_memrealtime around the tower
 // into a.dbg (the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back item 6) - no output depends on the stamps.
-template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0>
+// TT = 1: compact tap table + ring loop (k_loop_256_ring): the form for 18 row tiles (6x6, 8 boards); needs PERM and 16 % P == 0.
+template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0, int TT = 0>
 __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
@@ -1341,7 +1439,8 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     constexpr int LAYER_FRAGS = TAPS * 8 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* hscratch = reinterpret_cast<float*>(lds + NPL * PLANE);  // [2][RT*16] head pre-activations
-    int* tap_table = reinterpret_cast<int*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes]
+    int* tap_table = reinterpret_cast<int*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes], TT = 1: [TAPS][RT][PPT]
+    static_assert(!TT || (PERM && !SP && 16 % P == 0 && P >= 8), "compact tap table: square-major rows with whole 8-row runs per square");
     const int count = a.count_dev ? *a.count_dev : a.count_host;
     const int pos0 = blockIdx.x * P;
     if (pos0 >= count) return;
@@ -1398,7 +1497,19 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         const int plane = i >> 5, zr = (i >> 2) & 7, pc = i & 3;
         *reinterpret_cast<uint4*>(lds + plane * PLANE + (ZROW + zr) * LDS_ROWB + pc * 16) = make_uint4(0, 0, 0, 0);
     }
-    {   // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier): wave w computes
+    // TT = 1: a lane's fragment address = entry of its (tap, tile, square slot) + its own constant: board row and piece rotation
+    const int tslot = TT ? lr / P : 0;
+    const int lane_const = TT ? (lr % P) * LDS_ROWB + lds_piece(lr % P, q) : 0;
+    if constexpr (TT) {
+        for (int i = tid; i < TAPS * RT * RM::PPT; i += NT) {
+            const int tap = i / (RT * RM::PPT), rt = (i / RM::PPT) % RT, sl = i % RM::PPT;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int sq = RM::square_at(rt * RM::PPT + sl);
+            const int y = sq / NB + dy, x = sq % NB + dx;
+            const bool ok = sq >= 0 && y >= 0 && y < NB && x >= 0 && x < NB;
+            tap_table[i] = (ok ? RM::row_of(0, y * NB + x) : ZROW) * LDS_ROWB;   // off the board: the zero rows, same board phase
+        }
+    } else {   // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier): wave w computes
         // taps w and w + 8
         for (int tap = wave; tap < TAPS; tap += 8) {
             int tb[RT];
@@ -1408,6 +1519,10 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = tb[rt];
         }
     }
+    auto ta = [&](int tap, int rt) -> int {   // the lane's fragment base address of row tile rt under `tap`
+        if constexpr (TT) return tap_table[(tap * RT + rt) * RM::PPT + tslot] + lane_const;
+        else return tap_table[(tap * RT + rt) * 64 + lane];
+    };
     int obase[RN];
 #pragma unroll
     for (int j = 0; j < RN; j++) obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
@@ -1464,7 +1579,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
-                        const ex8 av = *reinterpret_cast<const ex8*>(lds + tap_table[(tap * RT + rt) * 64 + lane]);
+                        const ex8 av = *reinterpret_cast<const ex8*>(lds + ta(tap, rt));
 #pragma unroll
                         for (int j = 0; j < RN; j++) acc[rt][j] = Elem<ET>::mfma(bw[tap][j], av, acc[rt][j]);
                     }
@@ -1480,7 +1595,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int tap = 0; tap < TAPS; tap++) {
                 int abase[RT];
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
+                for (int rt = 0; rt < RT; rt++) abase[rt] = ta(tap, rt);
                 for (int kc = 0; kc < a.kc_in; kc++) {
                     ex8 bh[RN], bl[RN];
 #pragma unroll
@@ -1506,7 +1621,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int tap = 0; tap < (one_chunk ? 0 : TAPS); tap++) {
                 int abase[RT];
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) abase[rt] = tap_table[(tap * RT + rt) * 64 + lane];
+                for (int rt = 0; rt < RT; rt++) abase[rt] = ta(tap, rt);
                 for (int kc = 0; kc < a.kc_in; kc++) {
                     ex8 b[RN];
 #pragma unroll
@@ -1579,7 +1694,8 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
             };
-            if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 7)>(lds, tap_table, lane, acc, wl);
+            if constexpr (TT) k_loop_256_ring<NB, P, RN, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, acc, wl);
+            else if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 7)>(lds, tap_table, lane, acc, wl);
             else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
         }
         __syncthreads();
@@ -1744,7 +1860,8 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
             };
-            if constexpr (PERM) k_loop_256_skip<NB, P, RNP, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+            if constexpr (TT) k_loop_256_ring<NB, P, RNP, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, pacc, wlp);
+            else if constexpr (PERM) k_loop_256_skip<NB, P, RNP, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
             else k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
         }
 #pragma unroll
@@ -1921,29 +2038,59 @@ __global__ void plain_variance_kernel(const float* ube, const float* local, cons
     variance[pos] = fminf(fmaxf(fmaxf(expf(ube[pos]), loc), 0.f), 4.f);
 }
 
-// SimHash (net6_simhash.rs:208-256): sign bits of planes (to-move plane zeroed) x matrix[in][32]
-__global__ __launch_bounds__(64) void simhash_kernel(const float* planes, const float* matrix, const uint32_t* bitset,
-                                                     const int32_t* count_dev, int count_host, int nn, int cin,
-                                                     float* local, uint32_t* index_out) {
+// SimHash straight from the packed game states, 8 boards per workgroup (HashNetwork::get_indices, net6_simhash.rs:202-236): the
+// planes are built in LDS in the reference's flattening (k = plane * N*N + square, the black-to-move plane zeroed, :208-222), then
+// thread (board, bit) walks k once: one broadcast LDS read and one coalesced 128-B row of the [in_size][32] matrix per step.  The
+// first version (one wave per board) read the planes with a stride and re-fetched the 166 KB matrix per board: 249 us per 2048 6x6 positions
+// (13 % of a simulation); this one also makes the separate plane-encoding launch unnecessary on the MFMA path.
+template <int NB>
+__global__ __launch_bounds__(256) void simhash_state_kernel(const tz_state* states, const int32_t* game_index, const float* matrix,
+                                                            const uint32_t* bitset, const int32_t* count_dev, int count_host, float* local,
+                                                            uint32_t* index_out) {
+    constexpr int NN = NB * NB, CIN = 4 * NB + 12, IN = CIN * NN, BPW = 8, DW = sizeof(tz_state) / 4;
+    __shared__ tz_state st[BPW];
+    __shared__ float pl[BPW][IN];
+    __shared__ int fd[BPW];
     const int count = count_dev ? *count_dev : count_host;
-    const int pos = blockIdx.x, l = threadIdx.x;
-    if (pos >= count) return;
-    const int bit = l & 31, half = l >> 5;
-    const int in_size = nn * cin, skip = cin - 2;
+    const int pos0 = blockIdx.x * BPW, tid = threadIdx.x;
+    if (pos0 >= count) return;
+    const int nb = min(BPW, count - pos0);
+    for (int i = tid; i < nb * DW; i += 256) {
+        const int b = i / DW, d = i - b * DW, pos = pos0 + b;
+        reinterpret_cast<uint32_t*>(st)[i] = reinterpret_cast<const uint32_t*>(states + (game_index ? game_index[pos] : pos))[d];
+    }
+    __syncthreads();
+    if (tid < nb) fd[tid] = state_flat_diff<NB>(&st[tid]);
+    __syncthreads();
+    for (int i = tid; i < nb * IN; i += 256) {
+        const int b = i / IN, k = i - b * IN, c = k / NN, px = k - c * NN;
+        pl[b][k] = c == CIN - 2 ? 0.0f : plane_value<NB>(&st[b], px, c, fd[b]);
+    }
+    __syncthreads();
+    const int bit = tid & 31, b = tid >> 5;
     float s = 0.f;
-    for (int k = half; k < in_size; k += 2) {  // k = c*nn + px (reference flattening)
-        const int c = k / nn, px = k % nn;
-        if (c == skip) continue;
-        s += planes[((size_t)pos * nn + px) * cin + c] * matrix[(size_t)k * 32 + bit];
+    if (b < nb) {
+#pragma unroll 8
+        for (int k = 0; k < IN; k++) s += pl[b][k] * matrix[(size_t)k * 32 + bit];
     }
-    s += __shfl_xor(s, 32);
-    const unsigned long long m = __ballot(!(s < 0.0f) && l < 32);
-    const uint32_t index = (uint32_t)m;
-    if (l == 0) {
+    const unsigned long long m = __ballot(!(s < 0.0f));
+    const uint32_t index = (tid & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+    if (bit == 0 && b < nb) {
         const bool seen = bitset && ((bitset[index >> 5] >> (index & 31)) & 1u);
-        local[pos] = seen ? 0.0f : 4.0f;
-        if (index_out) index_out[pos] = index;
+        local[pos0 + b] = seen ? 0.0f : 4.0f;
+        if (index_out) index_out[pos0 + b] = index;
     }
+}
+
+int launch_simhash_state(int n, const tz_state* states, const int32_t* gidx, const float* matrix, const uint32_t* bitset,
+                         const int32_t* count_dev, int count_host, int max_positions, float* local, uint32_t* index_out, hipStream_t st) {
+    const int blocks = (max_positions + 7) / 8;
+    switch (n) {
+        case 4: simhash_state_kernel<4><<<blocks, 256, 0, st>>>(states, gidx, matrix, bitset, count_dev, count_host, local, index_out); break;
+        case 6: simhash_state_kernel<6><<<blocks, 256, 0, st>>>(states, gidx, matrix, bitset, count_dev, count_host, local, index_out); break;
+        default: return tz_fail(TZ_EINVAL, "simhash: the SimHash nets are 4x4 and 6x6");
+    }
+    return TZ_OK;
 }
 
 // HashNetwork::update_counts (net6_simhash.rs:238-243): set the bit of every index
@@ -2462,12 +2609,13 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0>
+template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
-    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + (size_t)9 * RT * 64 * sizeof(int);  // image + head scratch + tap table
+    constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * sizeof(int);
+    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
     static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
-    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL>;
+    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
     int attr_dev = 0;
     TZ_HIP(hipGetDevice(&attr_dev));
@@ -2504,6 +2652,11 @@ int net_small_p(int max_positions) {
     return max_positions <= 256 ? 1 : max_positions <= 512 ? 2 : max_positions <= 1024 ? 4 : 0;
 }
 
+bool net_p6_four() {
+    static const bool four = getenv("TZ_NET_P6") && !strcmp(getenv("TZ_NET_P6"), "4");
+    return four;
+}
+
 template <typename ET>
 int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t st) {
     const bool sq = net_square_major();
@@ -2531,7 +2684,11 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
         case 3: return sq ? launch_net<3, 1, ET, true>(a, max_positions, st) : launch_net<3, 1, ET, false>(a, max_positions, st);
         case 4: return launch_net<4, 1, ET, false>(a, max_positions, st);
         case 5: return sq ? launch_net<5, 1, ET, true>(a, max_positions, st) : launch_net<5, 1, ET, false>(a, max_positions, st);
-        case 6: return sq ? launch_net<6, 2, ET, true>(a, max_positions, st) : launch_net<6, 2, ET, false>(a, max_positions, st);
+        case 6:
+            // 8 boards per workgroup (18 row tiles, compact tap table, ring loop) once that still gives every CU a workgroup:
+            // the weight stream per MFMA halves against the 4-board form.  TZ_NET_P6=4 keeps the 4-board form (A/B).
+            if (sq && max_positions >= 2048 && !net_p6_four()) return launch_net<6, 2, ET, true, 8, 0, 0, 1>(a, max_positions, st);
+            return sq ? launch_net<6, 2, ET, true>(a, max_positions, st) : launch_net<6, 2, ET, false>(a, max_positions, st);
     }
     return tz_fail(TZ_EINVAL, "net: unsupported board size");
 }
@@ -2693,7 +2850,7 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     int rc;
     const bool bf = net->precision != TZ_PREC_F32;  // 16-bit MFMA path (bf16 or fp16 storage)
     const int nn = net->nn;
-    const bool need_planes = !bf || net->has_hash;
+    const bool need_planes = !bf;   // the MFMA path builds its planes in LDS; SimHash reads the packed states (simhash_state_kernel)
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
     const bool split = net->precision == TZ_PREC_F16X2;
@@ -2826,8 +2983,8 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
             rnd_finish_kernel<<<max_positions, 64, 0, st>>>(outs[0], outs[1], net->ube, count_dev, count_host, 512, 512, net->rnd_min,
                                                             net->rnd_max, net->variance);
     } else if (net->has_hash) {
-        simhash_kernel<<<max_positions, 64, 0, st>>>(net->planes, net->simhash, net->bitset, count_dev, count_host, nn, net->cin,
-                                                     net->aux, nullptr);
+        if ((rc = launch_simhash_state(net->n, states, gidx, net->simhash, net->bitset, count_dev, count_host, max_positions, net->aux, nullptr, st)))
+            return rc;
         plain_variance_kernel<<<(max_positions + 255) / 256, 256, 0, st>>>(net->ube, net->aux, count_dev, count_host, net->variance);
     } else {
         plain_variance_kernel<<<(max_positions + 255) / 256, 256, 0, st>>>(net->ube, nullptr, count_dev, count_host, net->variance);
@@ -3525,9 +3682,9 @@ int tz_net_hash_indices(tz_net* net, int batch, const tz_state* states, uint32_t
     uint32_t* didx = nullptr;
     hipError_t e = hipMalloc(&didx, batch * 4);
     if (e == hipSuccess) {
-        rc = encode(net, dstates, nullptr, nullptr, batch, batch, st);
+        rc = tz_net_ensure_batch(net, batch);
+        if (!rc) rc = launch_simhash_state(net->n, dstates, nullptr, net->simhash, net->bitset, nullptr, batch, batch, net->aux, didx, st);
         if (!rc) {
-            simhash_kernel<<<batch, 64, 0, st>>>(net->planes, net->simhash, net->bitset, nullptr, batch, net->nn, net->cin, net->aux, didx);
             if (update) bitset_set_kernel<<<(batch + 255) / 256, 256, 0, st>>>(net->bitset, didx, batch);
             if (indices_out) e = hipMemcpyAsync(indices_out, didx, batch * 4, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -24,7 +24,9 @@ def child(n, out):
             net = A.Net(arch=arch, n=n, blocks=3, precision=prec).load_tensors(W.init_weights(W.ARCH_TEST, n=n, blocks=3, seed=5))
         else:
             net = A.Net.new(arch=arch, seed=5, precision=prec)
-        for count in (1, 7, 16, 333, 515, 1030):   # ragged: counts that are not multiples of the boards per workgroup
+        # ragged: counts that are not multiples of the boards per workgroup; from 2048 positions on 6x6 runs 8-board workgroups
+        # (compact tap table, ring loop)
+        for count in (1, 7, 16, 333, 515, 1030) + ((2048, 2051) if n == 6 else ()):
             dummy = A.BatchedMCTS(count, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 8)
             rng = np.random.default_rng(count)
             dummy.new_openings(rng.integers(0, 16, count))
