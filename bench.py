@@ -188,7 +188,7 @@ def main():
     backend = os.environ.get("TZ_BENCH_BACKEND", "nccl")   # "gloo" (+ TZ_BENCH_DEVICE=0): explicit rehearsal of N ranks without RCCL
     if "TZ_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["TZ_BENCH_DEVICE"])
-    if world > 1:
+    if world > 1 or os.environ.get("TZ_BENCH_FORCE_DIST"):   # TZ_BENCH_FORCE_DIST=1: rehearse the N > 1 set-up with one rank
         import torch.distributed as dist_mod
 
         dist = dist_mod
@@ -240,6 +240,8 @@ def main():
                 dist.broadcast_object_list(box, 0)
                 comm = CM.Comm.fs(box[0], rank, world)
             comm.barrier()
+            probe = comm.all_gather(b"rank %d" % rank)    # fail here, not in the timed region, if the ring does not carry data
+            assert probe == [b"rank %d" % r for r in range(world)], probe
             sp.set_comm(comm, writer_rank=-1)   # every rank ends up with all the lines, as `learn` on any rank would need
         except Exception as e:
             sys.stderr.write("rank %d: the native exchange (tz_comm over %s) failed: %r\n" % (rank, backend, e))

@@ -2683,7 +2683,11 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
     switch (net->n) {
         case 3: return sq ? launch_net<3, 1, ET, true>(a, max_positions, st) : launch_net<3, 1, ET, false>(a, max_positions, st);
         case 4: return launch_net<4, 1, ET, false>(a, max_positions, st);
-        case 5: return sq ? launch_net<5, 1, ET, true>(a, max_positions, st) : launch_net<5, 1, ET, false>(a, max_positions, st);
+        case 5:
+#ifdef TZ_ABLATIONS   // A/B: the 5x5 kernel on the compact tap table + fragment ring of the 6x6 form (TZ_NET_TT=1)
+            if (sq && getenv("TZ_NET_TT") && atoi(getenv("TZ_NET_TT")) == 1) return launch_net<5, 1, ET, true, 8, 0, 0, 1>(a, max_positions, st);
+#endif
+            return sq ? launch_net<5, 1, ET, true>(a, max_positions, st) : launch_net<5, 1, ET, false>(a, max_positions, st);
         case 6:
             // 8 boards per workgroup (18 row tiles, compact tap table, ring loop) once that still gives every CU a workgroup:
             // the weight stream per MFMA halves against the 4-board form.  TZ_NET_P6=4 keeps the 4-board form (A/B).

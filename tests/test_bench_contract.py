@@ -52,10 +52,32 @@ def test_two_rank_launch_as_the_driver_does_it():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     # the line says what carried the exchange: here the rehearsal switches (gloo process group, shared-directory transport)
     assert out["backend"] == "gloo" and out["world"] == 2
-    assert out["exchange"]["transport"] == "fs" and out["exchange"]["world"] == 2 and out["exchange"]["collectives"] == 3 * 3
+    assert out["exchange"]["transport"] == "fs" and out["exchange"]["world"] == 2 and out["exchange"]["collectives"] == 1 + 3 * 3   # the probe + 3 gathers per move
     assert out["targets_gathered"] >= 0
     # whole-job aggregate: 2 ranks x 128 games x 33 simulate calls per move x 2 timed moves
     assert abs(out["value"] * out["ms_per_step"] * 2 / 1000.0 - 2 * 128 * 33 * 2) < 0.02 * 2 * 128 * 33 * 2
+
+
+@pytest.mark.gpu
+def test_the_rccl_set_up_of_a_multi_gpu_run_with_one_rank():
+    """What the driver's N > 1 launch does before the timed region, on this box's one GPU (TZ_BENCH_FORCE_DIST=1): torchrun,
+    process group over nccl (= RCCL), the all_reduce probe, the communicator id broadcast through it, the library's own RCCL
+    communicator (ncclCommInitRank on PyTorch's RCCL copy - one RCCL, one HIP runtime in the process), the data probe.  The
+    line must name them."""
+    env = dict(os.environ, TZ_BENCH_FORCE_DIST="1")
+    for k in ("TZ_BENCH_BACKEND", "TZ_BENCH_DEVICE", "TZ_BENCH_EXCHANGE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--games", "256",
+           "--sims", "32", "--no-cpu-baseline", "--no-precision-report"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-800:]
+    out = json.loads(lines[0])
+    assert out["backend"] == "nccl" and out["world"] == 1 and out["n_gpus"] == 1
+    assert out["exchange"]["transport"] == "rccl" and out["exchange"]["api"].startswith("tz_comm") and out["exchange"]["collectives"] >= 1
+    assert "double free" not in r.stderr and "Aborted" not in r.stderr
 
 
 @pytest.mark.gpu
