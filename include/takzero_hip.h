@@ -215,6 +215,12 @@ int tz_search_root_info(tz_search* s, tz_root_info* out /*[batch]*/);
 int tz_search_root_children(tz_search* s, int amax, uint16_t* move_idx, uint32_t* visits,
                             uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob,
                             float* std_dev);
+/* Below the root: the reference's Node.children is a public field (node/mod.rs:14-23) that puzzle and visualize_search read.
+ * The node reached from game `game`'s root by the moves path[0..path_len) (move indices; path_len 0 = the root): node_out = its
+ * statistics (ply = the root's ply + path_len; is_terminal_env = Node::is_terminal), children rows of width amax as in
+ * tz_search_root_children (any pointer may be NULL).  TZ_EINVAL if the path leaves the tree. */
+int tz_search_node(tz_search* s, int game, const uint16_t* path, int path_len, tz_root_info* node_out, int amax, uint16_t* move_idx,
+                   uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob, float* std_dev);
 /* Node::select_best_action per root (node/mod.rs:132-161). 0xFFFF for roots without children. */
 int tz_search_select_best_actions(tz_search* s, uint16_t* actions_out /*[batch]*/);
 /* Node::improved_policy(visitations) per root (policy.rs:23-48), [batch][amax]. */

@@ -484,3 +484,43 @@ int tzo_host_reanalyze_target(tzo_search* s, int g, uint16_t selected, int amax,
 }
 
 }  // extern "C"
+
+// ---- a node below the root (mirror of tz_search_node) ----
+extern "C" int tzo_search_node(tzo_search* s, int game, const uint16_t* path, int path_len, tz_root_info* node_out, int amax, uint16_t* move_idx,
+                               uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob, float* std_dev) {
+    const Node<TakEnv>* node = &s->mcts->nodes[game];
+    for (int d = 0; d < path_len; d++) {
+        const Node<TakEnv>* next = nullptr;
+        for (auto& c : node->children)
+            if (c.first == (int)path[d]) {
+                next = &c.second;
+                break;
+            }
+        if (!next) return -1;
+        node = next;
+    }
+    if ((int)node->children.size() > amax) return -1;
+    if (node_out) {
+        memset(node_out, 0, sizeof *node_out);
+        node_out->visit_count = node->visit_count;
+        node_out->n_children = (uint32_t)node->children.size();
+        node_out->eval_tag = node->evaluation.tag;
+        node_out->eval.ply = node->evaluation.bits();
+        node_out->std_dev = node->std_dev;
+        node_out->logit = node->logit;
+        node_out->probability = node->probability;
+        node_out->ply = (uint16_t)(s->mcts->envs[game].steps() + path_len);
+        node_out->is_terminal_env = node->is_terminal();
+    }
+    for (size_t i = 0; i < node->children.size(); i++) {
+        const Node<TakEnv>& c = node->children[i].second;
+        if (move_idx) move_idx[i] = (uint16_t)node->children[i].first;
+        if (visits) visits[i] = c.visit_count;
+        if (eval_tag) eval_tag[i] = c.evaluation.tag;
+        if (eval_bits) eval_bits[i] = c.evaluation.bits();
+        if (logit) logit[i] = c.logit;
+        if (prob) prob[i] = c.probability;
+        if (std_dev) std_dev[i] = c.std_dev;
+    }
+    return 0;
+}

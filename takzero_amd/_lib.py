@@ -27,7 +27,7 @@ SYMBOLS = [
     "tz_net_load_weights_mem", "tz_net_destroy", "tz_net_eval", "tz_net_encode", "tz_net_forward_raw", "tz_net_hash_indices", "tz_net_load_bitset", "tz_net_save_bitset",
     "tz_search_create", "tz_search_destroy", "tz_search_set_positions", "tz_search_get_positions",
     "tz_search_new_openings", "tz_search_simulate", "tz_search_apply_noise", "tz_search_root_info",
-    "tz_search_root_children", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
+    "tz_search_root_children", "tz_search_node", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
     "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync", "tz_search_pool_usage",
     "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_debug_net_clock", "tz_search_terminal_details", "tz_search_play_moves",
     "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
@@ -117,6 +117,7 @@ def load():
     lib.tz_search_apply_noise.argtypes = [vp, vp, ci, cf]
     lib.tz_search_root_info.argtypes = [vp, vp]
     lib.tz_search_root_children.argtypes = [vp, ci] + [vp] * 7
+    lib.tz_search_node.argtypes = [vp, ci, vp, ci, vp, ci] + [vp] * 7
     lib.tz_search_select_best_actions.argtypes = [vp, vp]
     lib.tz_search_improved_policy.argtypes = [vp, cf, ci, vp]
     lib.tz_search_improved_policy_each.argtypes = [vp, vp, ci, vp]

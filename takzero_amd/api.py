@@ -292,6 +292,21 @@ class BatchedMCTS:
             "move_idx", "visits", "eval_tag", "eval_bits", "logit", "prob", "std_dev")]))
         return out
 
+    def node(self, game, path, amax=None):
+        """The node reached from game `game`'s root by the moves of `path` (Node.children below the root, node/mod.rs:14-23):
+        (info record, children dict as root_children for that one node)."""
+        if amax is None:
+            amax = 512 if self.n < 6 else 1024
+        p = np.ascontiguousarray(path, dtype=np.uint16)
+        info = np.zeros(1, ROOT_INFO_DTYPE)
+        out = dict(move_idx=np.zeros(amax, np.uint16), visits=np.zeros(amax, np.uint32), eval_tag=np.zeros(amax, np.uint8),
+                   eval_bits=np.zeros(amax, np.uint32), logit=np.zeros(amax, np.float32), prob=np.zeros(amax, np.float32),
+                   std_dev=np.zeros(amax, np.float32))
+        check(self.lib.tz_search_node(self.h, game, p.ctypes.data if len(p) else None, len(p), info.ctypes.data, amax,
+                                      *[out[k].ctypes.data for k in ("move_idx", "visits", "eval_tag", "eval_bits", "logit", "prob", "std_dev")]))
+        nc = int(info[0]["n_children"])
+        return info[0], {k: v[:nc] for k, v in out.items()}
+
     def select_best_actions(self):
         out = np.zeros(self.batch, np.uint16)
         check(self.lib.tz_search_select_best_actions(self.h, out.ctypes.data))

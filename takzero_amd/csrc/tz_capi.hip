@@ -399,6 +399,62 @@ int tz_search_root_children(tz_search* s, int amax, uint16_t* move_idx, uint32_t
     return TZ_OK;
 }
 
+int tz_search_node(tz_search* s, int game, const uint16_t* path, int path_len, tz_root_info* node_out, int amax, uint16_t* move_idx,
+                   uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob, float* std_dev) {
+    if (!s || game < 0 || game >= s->d.batch || path_len < 0 || path_len > TZ_MAX_DEPTH || (path_len && !path) || amax <= 0)
+        return tz_fail(TZ_EINVAL, "tz_search_node: bad argument");
+    TZ_HIP(hipSetDevice(s->device));
+    const size_t cells = (size_t)amax;
+    int rc = ensure_child(s, cells * (2 + 4 + 1 + 4 + 4 + 4 + 4 + 8) + 64 + 2 * (size_t)TZ_MAX_DEPTH + 64);
+    if (rc) return rc;
+    unsigned char* base = (unsigned char*)s->child_dev;
+    uint32_t* d_vis = (uint32_t*)base;
+    uint32_t* d_bits = d_vis + cells;
+    float* d_logit = (float*)(d_bits + cells);
+    float* d_prob = d_logit + cells;
+    float* d_std = d_prob + cells;
+    uint32_t* d_words = (uint32_t*)(d_std + cells);     // 8 words
+    int* d_status = (int*)(d_words + 8);
+    uint16_t* d_move = (uint16_t*)(d_status + 2);
+    uint16_t* d_path = d_move + cells;
+    uint8_t* d_tag = (uint8_t*)(d_path + TZ_MAX_DEPTH);
+    if (path_len) TZ_HIP(hipMemcpyAsync(d_path, path, (size_t)path_len * 2, hipMemcpyHostToDevice, s->stream));
+    if ((rc = tz_tree_node(s->d, game, d_path, path_len, d_words, d_status, amax, d_move, d_vis, d_tag, d_bits, d_logit, d_prob, d_std, s->stream)))
+        return rc;
+    uint32_t words[8];
+    int status = 0;
+    TZ_HIP(hipMemcpyAsync(words, d_words, sizeof words, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipMemcpyAsync(&status, d_status, sizeof status, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipStreamSynchronize(s->stream));
+    if (status >= 0) return tz_fail(TZ_EINVAL, "tz_search_node: the path leaves the tree at depth " + std::to_string(status));
+    if ((int)words[1] > amax) return tz_fail(TZ_EINVAL, "tz_search_node: amax smaller than the node's child count");
+    if (node_out) {
+        std::vector<tz_root_info> info(s->d.batch);
+        if ((rc = tz_search_root_info(s, info.data()))) return rc;
+        tz_root_info r;
+        memset(&r, 0, sizeof r);
+        r.visit_count = words[0];
+        r.n_children = words[1];
+        r.eval_tag = (uint8_t)words[2];
+        r.eval.ply = words[3];
+        memcpy(&r.std_dev, &words[4], 4);
+        memcpy(&r.logit, &words[5], 4);
+        memcpy(&r.probability, &words[6], 4);
+        r.ply = (uint16_t)(info[game].ply + path_len);
+        r.is_terminal_env = r.eval_tag != TZ_EVAL_VALUE && r.eval.ply == 0;   // Node::is_terminal (node/mod.rs:106-108)
+        *node_out = r;
+    }
+    if (move_idx) TZ_HIP(hipMemcpyAsync(move_idx, d_move, cells * 2, hipMemcpyDeviceToHost, s->stream));
+    if (visits) TZ_HIP(hipMemcpyAsync(visits, d_vis, cells * 4, hipMemcpyDeviceToHost, s->stream));
+    if (eval_tag) TZ_HIP(hipMemcpyAsync(eval_tag, d_tag, cells, hipMemcpyDeviceToHost, s->stream));
+    if (eval_bits) TZ_HIP(hipMemcpyAsync(eval_bits, d_bits, cells * 4, hipMemcpyDeviceToHost, s->stream));
+    if (logit) TZ_HIP(hipMemcpyAsync(logit, d_logit, cells * 4, hipMemcpyDeviceToHost, s->stream));
+    if (prob) TZ_HIP(hipMemcpyAsync(prob, d_prob, cells * 4, hipMemcpyDeviceToHost, s->stream));
+    if (std_dev) TZ_HIP(hipMemcpyAsync(std_dev, d_std, cells * 4, hipMemcpyDeviceToHost, s->stream));
+    TZ_HIP(hipStreamSynchronize(s->stream));
+    return TZ_OK;
+}
+
 int tz_search_shape(tz_search* s, int* batch_out, int* board_n_out, int* half_komi_out, int* max_actions_out) {
     if (!s) return tz_fail(TZ_EINVAL, "tz_search_shape: null handle");
     if (batch_out) *batch_out = s->d.batch;

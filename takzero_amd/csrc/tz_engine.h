@@ -78,6 +78,9 @@ int tz_tree_apply_noise(const SearchDev& s, const float* noise_dev, int amax, fl
 int tz_tree_root_info(const SearchDev& s, tz_root_info* out_dev, hipStream_t st);
 int tz_tree_root_children(const SearchDev& s, int amax, uint16_t* move_idx, uint32_t* visits, uint8_t* eval_tag,
                           uint32_t* eval_bits, float* logit, float* prob, float* std_dev, hipStream_t st);
+int tz_tree_node(const SearchDev& s, int game, const uint16_t* path_dev, int len, uint32_t* out_words, int* status, int amax,
+                 uint16_t* move_idx, uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob, float* std_dev,
+                 hipStream_t st);
 int tz_tree_select_best(const SearchDev& s, uint16_t* out_dev, hipStream_t st);
 int tz_tree_step(const SearchDev& s, const uint16_t* actions_dev, hipStream_t st);
 int tz_tree_restart(const SearchDev& s, const int32_t* choice_dev, int8_t* terminal_dev, bool force_all,

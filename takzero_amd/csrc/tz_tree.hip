@@ -507,6 +507,56 @@ __global__ __launch_bounds__(64) void root_children_kernel(SearchDev s, int amax
     }
 }
 
+// A node below the root (Node.children is a public field of the reference, node/mod.rs:14-23, read by puzzle / visualize_search):
+// one wave walks `path` (move indices) from game g's root; status = -1 found, else the depth at which the path left the tree.
+// out_words: [0] visits [1] nchild [2] tag [3] bits [4] std_dev [5] logit [6] prob; children rows as root_children_kernel.
+__global__ __launch_bounds__(64) void node_kernel(SearchDev s, int g, const uint16_t* path, int len, uint32_t* out_words, int* status,
+                                                  int amax, uint16_t* move_idx, uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits,
+                                                  float* logit, float* prob, float* std_dev) {
+    const int l = lane_id();
+    const size_t base = slab_base(s, s.bank[g], g);
+    size_t node = base;
+    for (int d = 0; d < len; d++) {
+        const int nc = s.t.nchild[node];
+        const uint32_t c0 = s.t.child0[node];
+        int found = -1;
+        for (int i0 = 0; i0 < nc && found < 0; i0 += 64) {
+            const int i = i0 + l;
+            const bool hit = i < nc && s.t.action[base + c0 + i] == path[d];
+            const unsigned long long m = __ballot(hit);
+            if (m) found = i0 + __ffsll((long long)m) - 1;
+        }
+        if (found < 0) {
+            if (l == 0) *status = d;
+            return;
+        }
+        node = base + c0 + found;
+    }
+    const int nc = s.t.nchild[node];
+    const uint32_t c0 = s.t.child0[node];
+    if (l == 0) {
+        *status = -1;
+        out_words[0] = s.t.visits[node];
+        out_words[1] = (uint32_t)nc;
+        out_words[2] = s.t.eval_tag[node];
+        out_words[3] = s.t.eval_bits[node];
+        out_words[4] = __float_as_uint(s.t.std_dev[node]);
+        out_words[5] = __float_as_uint(s.t.logit[node]);
+        out_words[6] = __float_as_uint(s.t.prob[node]);
+    }
+    for (int i = l; i < amax; i += 64) {
+        const bool in = i < nc;
+        const size_t ci = base + c0 + i;
+        move_idx[i] = in ? s.t.action[ci] : 0;
+        visits[i] = in ? s.t.visits[ci] : 0;
+        eval_tag[i] = in ? s.t.eval_tag[ci] : 0;
+        eval_bits[i] = in ? s.t.eval_bits[ci] : 0;
+        logit[i] = in ? s.t.logit[ci] : 0.0f;
+        prob[i] = in ? s.t.prob[ci] : 0.0f;
+        std_dev[i] = in ? s.t.std_dev[ci] : 0.0f;
+    }
+}
+
 // Node::select_best_action, node/mod.rs:132-161
 __global__ __launch_bounds__(64) void select_best_kernel(SearchDev s, uint16_t* out) {
     const int g = blockIdx.x, l = lane_id();
@@ -867,6 +917,13 @@ int tz_tree_root_info(const SearchDev& s, tz_root_info* out_dev, hipStream_t st)
 int tz_tree_root_children(const SearchDev& s, int amax, uint16_t* move_idx, uint32_t* visits, uint8_t* eval_tag,
                           uint32_t* eval_bits, float* logit, float* prob, float* std_dev, hipStream_t st) {
     root_children_kernel<<<s.batch, 64, 0, st>>>(s, amax, move_idx, visits, eval_tag, eval_bits, logit, prob, std_dev);
+    TZ_LAUNCH_CHECK();
+    return TZ_OK;
+}
+int tz_tree_node(const SearchDev& s, int game, const uint16_t* path_dev, int len, uint32_t* out_words, int* status, int amax,
+                 uint16_t* move_idx, uint32_t* visits, uint8_t* eval_tag, uint32_t* eval_bits, float* logit, float* prob, float* std_dev,
+                 hipStream_t st) {
+    node_kernel<<<1, 64, 0, st>>>(s, game, path_dev, len, out_words, status, amax, move_idx, visits, eval_tag, eval_bits, logit, prob, std_dev);
     TZ_LAUNCH_CHECK();
     return TZ_OK;
 }

@@ -255,6 +255,25 @@ class OracleSearch:
         assert rc == 0
         return out
 
+    def node(self, game, path, amax=512):
+        """Mirror of BatchedMCTS.node: None if the path leaves the tree."""
+        import ctypes as C
+
+        from takzero_amd._lib import ROOT_INFO_DTYPE
+
+        p = np.ascontiguousarray(path, dtype=np.uint16)
+        info = np.zeros(1, ROOT_INFO_DTYPE)
+        out = dict(move_idx=np.zeros(amax, np.uint16), visits=np.zeros(amax, np.uint32), eval_tag=np.zeros(amax, np.uint8),
+                   eval_bits=np.zeros(amax, np.uint32), logit=np.zeros(amax, np.float32), prob=np.zeros(amax, np.float32),
+                   std_dev=np.zeros(amax, np.float32))
+        self.lib.tzo_search_node.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        rc = self.lib.tzo_search_node(self.h, game, p.ctypes.data if len(p) else None, len(p), info.ctypes.data, amax,
+                                      *[out[k].ctypes.data for k in ("move_idx", "visits", "eval_tag", "eval_bits", "logit", "prob", "std_dev")])
+        if rc != 0:
+            return None
+        nc = int(info[0]["n_children"])
+        return info[0], {k: v[:nc] for k, v in out.items()}
+
     def select_best_actions(self):
         out = np.zeros(self.batch, np.uint16)
         self.lib.tzo_search_select_best_actions(self.h, out.ctypes.data)

@@ -239,3 +239,41 @@ def test_device_f32_primitives_match_host(oracle):
     want = np.array([oracle.tzo_powif(0.997, int(v)) for v in k], np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(run(5, a, b).view(np.uint32), ((a + b) * a).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,agent", [(4, 2), (5, 1)])
+def test_nodes_below_the_root_match_the_oracle(oracle, n, agent):
+    """Node.children is a public field of the reference (node/mod.rs:14-23; puzzle and visualize_search walk it): tz_search_node
+    returns the node reached by a path of moves - statistics and children, bit for bit the oracle's - down the principal
+    variation of every game, and refuses a path that leaves the tree."""
+    A = require_gpu()
+    B, sims = 12, 300
+    gpu = A.BatchedMCTS(B, n, 4, agent_kind=agent, node_capacity=1 << 15)
+    ora = O.OracleSearch(oracle, B, n, 4, agent_kind=agent)
+    choice = np.arange(B) % 16
+    gpu.new_openings(choice)
+    ora.new_openings(choice)
+    betas = np.where(np.arange(B) % 2 == 0, 0.0, 0.25).astype(np.float32)
+    gpu.simulate(betas, sims)
+    ora.simulate(betas, sims)
+    deepest = 0
+    for g in range(B):
+        path = []
+        while True:
+            got, want = gpu.node(g, path), ora.node(g, path)
+            assert want is not None
+            for f in ("visit_count", "n_children", "eval_tag", "eval_bits", "std_dev", "logit", "probability", "ply", "is_terminal_env"):
+                assert got[0][f] == want[0][f] or (np.isnan(got[0][f]) and np.isnan(want[0][f])), (g, path, f)
+            for f in ("move_idx", "visits", "eval_tag", "eval_bits", "logit", "prob", "std_dev"):
+                assert np.array_equal(got[1][f].view(np.uint8), want[1][f].view(np.uint8)), (g, path, f)
+            if len(got[1]["visits"]) == 0 or got[1]["visits"].max() == 0:
+                break
+            path.append(int(got[1]["move_idx"][int(np.argmax(got[1]["visits"]))]))   # most visited child
+        deepest = max(deepest, len(path))
+        root_moves = set(int(m) for m in gpu.node(g, [])[1]["move_idx"])
+        absent = next(m for m in range(A.policy_size(n)) if m not in root_moves)
+        with pytest.raises(A.TakzeroError):
+            gpu.node(g, [absent])
+        assert ora.node(g, [absent]) is None
+    assert deepest >= 2
