@@ -1000,6 +1000,12 @@ struct RowMap {
     // the square at place k of the order (or -1: padding)
     __host__ __device__ static constexpr int square_at(int k) {
         if (k >= NN) return -1;
+        if (PERM && NB == 5 && P == 4) {  // fours (the split-precision kernel): the same tiles as the pair order below, and inside a four
+                                          // the places alternate with the checkerboard colour of the square, as on 6x6: the 4-row runs
+                                          // of a lane group then never share a piece rotation (LDS bank conflicts 19.5 % -> see profiles)
+            constexpr int T[25] = {2, 1, 4, 3, 10, 5, 20, 15, 22, 21, 24, 23, 14, 9, 6, 19, 8, 7, 12, 11, 16, 13, 18, 17, 0};
+            return T[k];
+        }
         if (PERM && NB == 5) {  // pairs along the top, left, bottom and right edges (3 taps each), one edge square left over with
                                 // the interior, and a corner alone in the half-empty last tile (5 taps): 26 of 117 pairs skipped
             constexpr int T[25] = {1, 2, 3, 4, 5, 10, 15, 20, 21, 22, 23, 24, 9, 14, 19, 6, 7, 8, 11, 12, 13, 16, 17, 18, 0};
@@ -1023,6 +1029,10 @@ struct RowMap {
     }
     // the inverse of square_at (tables: checked against it at compile time, row_map_is_permutation)
     __host__ __device__ static constexpr int place_of(int square) {
+        if (PERM && NB == 5 && P == 4) {
+            constexpr int I[25] = {24, 1, 0, 3, 2, 5, 14, 17, 16, 13, 4, 19, 18, 21, 12, 7, 20, 23, 22, 15, 6, 9, 8, 11, 10};
+            return I[square];
+        }
         if (PERM && NB == 5) {
             constexpr int I[25] = {24, 0, 1, 2, 3, 4, 15, 16, 17, 12, 5, 18, 19, 20, 13, 6, 21, 22, 23, 14, 7, 8, 9, 10, 11};
             return I[square];
@@ -1102,6 +1112,7 @@ static_assert(row_map_is_permutation<5, 8, true>() && row_map_is_permutation<6, 
 static_assert(row_map_pairs_issued<5, 8, true>() == 91 && row_map_pairs_issued<5, 8, false>() == 117, "5x5: 26 of 117 pairs skipped");
 static_assert(row_map_pairs_issued<6, 4, true>() == 69 && row_map_pairs_issued<3, 16, true>() == 49, "6x6: 12 of 81, 3x3: 32 of 81");
 static_assert(row_map_is_permutation<6, 8, true>() && row_map_pairs_issued<6, 8, true>() == 132, "6x6 with 8 boards: 30 of 162 pairs skipped");
+static_assert(row_map_is_permutation<5, 4, true>() && row_map_pairs_issued<5, 4, true>() == 49, "5x5 with 4 boards (split precision): 14 of 63 pairs skipped");
 
 // tap table entries of a lane under a row map (the general form of tap_bases_rc)
 template <int NB, int P, bool PERM, int LAYOUT>
