@@ -492,7 +492,9 @@ int ot_read_archive(const unsigned char* data, size_t bytes, NamedTensors& out) 
             t.dims.push_back((uint32_t)dv);
             total *= (uint64_t)dv;
         }
-        if (total > (1ull << 31)) return tz_fail(TZ_EPARSE, "model archive: tensor " + k->s + " is too large");
+        // a variable is a view of its own storage: more elements than the storage holds means a damaged size tuple (and must not
+        // become an allocation)
+        if (total > numel_storage) return tz_fail(TZ_EPARSE, "model archive: tensor " + k->s + " is larger than its storage");
         t.data.resize(total);
         const unsigned char* base = data + e.offset;
         std::vector<int64_t> idx(v->dims.size(), 0);

@@ -212,3 +212,57 @@ def test_net_load_ot_equals_load_tensors(tmp_path):
     for x, y in zip(ra, rb):
         assert np.array_equal(np.asarray(x), np.asarray(y))
     assert np.array_equal(a.hash_indices(states), b.hash_indices(states))
+
+
+def test_native_reader_under_sanitizers_on_damaged_archives(tmp_path):
+    """csrc/tz_ot.cpp compiled alone with -fsanitize=address,undefined and fed 400 damaged copies of a real archive: random byte
+    flips in the zip records, the pickle program and the storages, truncations at random points, spliced garbage.  Every file must
+    come back as loaded or TZ_EPARSE; the sanitizers must stay silent (a reader of files that another process is still writing)."""
+    import subprocess
+
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ot_fuzz")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "tests", "ot_fuzz_harness.cpp"), os.path.join(root, "takzero_amd", "csrc", "tz_ot.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the harness here: " + r.stderr[-400:])
+    w = W.init_weights(W.ARCH_TEST, n=3, blocks=1, seed=2)
+    w = {k: v for k, v in w.items() if v.size < 5000}          # keep the file small: the structure is what is attacked
+    good = ot.save_ot(tmp_path / "good.ot", w)
+    blob = bytearray(open(good, "rb").read())
+    rng = np.random.default_rng(0)
+    pkl_at = bytes(blob).index(b"\x80\x02c__torch__")
+    eocd_at = bytes(blob).rindex(b"PK\x05\x06")
+    cd_at = bytes(blob).index(b"PK\x01\x02")
+    files = [good]
+    for i in range(400):
+        b = bytearray(blob)
+        kind = i % 5
+        if kind == 0:      # flips anywhere
+            for at in rng.integers(0, len(b), int(rng.integers(1, 8))):
+                b[at] = int(rng.integers(0, 256))
+        elif kind == 1:    # flips in the pickle program
+            for at in rng.integers(pkl_at, pkl_at + 1500, int(rng.integers(1, 6))):
+                b[at] = int(rng.integers(0, 256))
+        elif kind == 2:    # flips in the central directory / end records (sizes, offsets, counts)
+            for at in rng.integers(cd_at, len(b), int(rng.integers(1, 6))):
+                b[at] = int(rng.integers(0, 256))
+        elif kind == 3:    # truncation
+            b = b[:int(rng.integers(0, len(b)))]
+        else:              # a spliced run of garbage
+            at = int(rng.integers(0, len(b) - 64))
+            b[at:at + 64] = bytes(rng.integers(0, 256, 64, dtype=np.uint8))
+        path = tmp_path / ("bad%03d.ot" % i)
+        path.write_bytes(bytes(b))
+        files.append(str(path))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1")
+    out = subprocess.run([exe] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, (out.stdout[-300:], out.stderr[-3000:])
+    fields = dict(zip(out.stdout.split()[::2], out.stdout.split()[1::2]))
+    assert int(fields["ok"]) >= 1 and int(fields["other"]) == 0 and int(fields["ok"]) + int(fields["parse_errors"]) == len(files)
+    assert int(fields["parse_errors"]) > 150 and eocd_at > cd_at
