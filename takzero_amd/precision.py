@@ -41,14 +41,34 @@ def trained_scale_weights(arch, states, seed=123, n=0, blocks=0, device=0):
                            2.0 / max(1e-6, float(np.abs(ube).max())))
 
 
-def errors_against_f32(arch, weights, states, precisions=("f16", "f16x2", "bf16"), n=0, blocks=0, device=0):
-    """{precision: {max_abs_logit_err, max_abs_value_err, max_abs_ube_err}} + the fp32 path's output scale."""
+def legal_mask(states, n, half_komi=4):
+    """[len(states)][policy_size] bool: the legal moves of every position (the children a root gets from the engine's own move
+    generation) - the logits a search ever reads (net5.rs:239-267 gathers exactly these)."""
+    m = A.BatchedMCTS(len(states), n, half_komi, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 10)
+    m.set_positions(np.arange(len(states)), states)
+    m.simulate(np.zeros(len(states), np.float32), 1)
+    info = m.root_info()
+    ch = m.root_children(int(max(1, info["n_children"].max())))
+    mask = np.zeros((len(states), A.policy_size(n)), bool)
+    for g in range(len(states)):
+        mask[g, ch["move_idx"][g, :int(info["n_children"][g])]] = True
+    m.close()
+    return mask
+
+
+def errors_against_f32(arch, weights, states, precisions=("f16", "f16x2", "bf16"), n=0, blocks=0, device=0, legal=None):
+    """{precision: {max_abs_logit_err, max_abs_value_err, max_abs_ube_err}} + the fp32 path's output scale.  With `legal` (a mask
+    from legal_mask) also the same over the legal-move logits only: a trained net's illegal-move logits are masked out of its loss
+    and drift far from the scale of the ones a search reads."""
     ref = A.Net(arch=arch, n=n, device=device, precision=A.PREC_F32, blocks=blocks)
     ref.load_tensors(weights)
     pol0, val0, ube0 = ref.forward_raw(states)
     ref.close()
     out = {"reference": "TZ_PREC_F32 (fp32 FMA kernels of this library)", "positions": int(len(states)),
            "logit_scale": float(np.abs(pol0).max()), "value_scale": float(np.abs(val0).max()), "ube_scale": float(np.abs(ube0).max())}
+    if legal is not None:
+        out["legal_logit_scale"] = float(np.abs(pol0[legal]).max())
+        out["legal_logit_std"] = float(pol0[legal].std())
     for name in precisions:
         net = A.Net(arch=arch, n=n, device=device, precision=A.PREC_NAMES[name], blocks=blocks)
         net.load_tensors(weights)
@@ -56,4 +76,6 @@ def errors_against_f32(arch, weights, states, precisions=("f16", "f16x2", "bf16"
         net.close()
         out[name] = {"max_abs_logit_err": float(np.abs(pol - pol0).max()), "max_abs_value_err": float(np.abs(val - val0).max()),
                      "max_abs_ube_err": float(np.abs(ube - ube0).max())}
+        if legal is not None:
+            out[name]["max_abs_legal_logit_err"] = float(np.abs(pol - pol0)[legal].max())
     return out
