@@ -148,21 +148,25 @@ def test_f32_path_at_trained_logit_scale(oracle):
     assert err["policy"] < 1e-4 and err["value"] < 1e-4 and err["ube"] < 1e-4
 
 
-def test_forward_is_batch_composition_independent(oracle):
+@pytest.mark.parametrize("prec,n", [(0, 5), (2, 5), (3, 5), (3, 6), (3, 4), (3, 3)])
+def test_forward_is_batch_composition_independent(oracle, prec, n):
     """A position's outputs do not depend on its slot or its neighbours (needed so that the oracle can
-    replay the engine's network calls one position at a time)."""
+    replay the engine's network calls one position at a time): bf16, fp16 and the split-precision kernel (whose workgroups hold
+    half the boards: 4 / 2 / 6 / 8 on 5x5 / 6x6 / 4x4 / 3x3), ragged batch sizes incl. a single position."""
     A = require_gpu()
     from takzero_amd import weights as W
 
-    w = W.init_weights(W.ARCH_TEST, n=5, blocks=2, seed=5)
-    net = A.Net(arch=A.ARCH_TEST, n=5, precision=A.PREC_BF16, blocks=2)
+    w = W.init_weights(W.ARCH_TEST, n=n, blocks=2, seed=5)
+    net = A.Net(arch=A.ARCH_TEST, n=n, precision=prec, blocks=2)
     net.load_tensors(w)
-    states = random_positions(oracle, O, 5, 4, 37, 9)
+    states = random_positions(oracle, O, n, 4, 37, 9)
     arr = O.states_array(states)
     pol, val, ube = net.forward_raw(arr)
-    perm = np.random.default_rng(0).permutation(37)[:11]
-    pol2, val2, ube2 = net.forward_raw(arr[perm])
-    assert np.array_equal(pol[perm], pol2) and np.array_equal(val[perm], val2) and np.array_equal(ube[perm], ube2)
+    rng = np.random.default_rng(0)
+    for count in (11, 1, 5, 2):
+        perm = rng.permutation(37)[:count]
+        pol2, val2, ube2 = net.forward_raw(arr[perm])
+        assert np.array_equal(pol[perm], pol2) and np.array_equal(val[perm], val2) and np.array_equal(ube[perm], ube2), count
 
 
 def test_failed_load_keeps_old_weights(oracle, tmp_path):
