@@ -94,6 +94,7 @@ int zip_entries(const unsigned char* d, size_t n, std::vector<ZipEntry>& out) {
         if (lho + 30 > n || rd32(d + lho) != 0x04034b50u) return tz_fail(TZ_EPARSE, "model archive: bad local header of " + e.name);
         e.offset = lho + 30 + rd16(d + lho + 26) + rd16(d + lho + 28);
         if (e.offset + e.csize > n) return tz_fail(TZ_EPARSE, "model archive: entry " + e.name + " runs past the end of the file");
+        if (e.method == 0 && e.usize != e.csize) return tz_fail(TZ_EPARSE, "model archive: stored entry " + e.name + " with two different sizes");
         out.push_back(e);
         p += 46 + fl + xl + cl;
     }
