@@ -22,10 +22,10 @@ def _setup(A, n=4, B=48, seed=7):
     return net, A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 13)
 
 
-def _check_lines(oracle, n, targets, replays, search):
+def _check_lines(oracle, n, targets, replays, search, game_values=True):
     from takzero_amd import formats as F
 
-    assert targets and replays
+    assert targets and (replays or replays is None)
     for line in targets.decode().splitlines(keepends=True):
         st, mv, pol, value, ube = F.parse_target(line, n, 4)
         legal = O.possible_moves(oracle, O.TzState.from_buffer_copy(np.array([st]).tobytes()))
@@ -33,12 +33,14 @@ def _check_lines(oracle, n, targets, replays, search):
         total = float(pol.sum(dtype=np.float64))
         assert abs(total - 1.0) < (0.15 if search == "puct" else 1e-3)
         assert 0.0 <= ube <= 4.0
-        if value != 0.0:                                    # +-0.997^k, k >= 1 plies before the end
+        if not game_values:                                 # reanalyze: the search's own root value (reanalyze/src/main.rs:214-224)
+            assert -1.0 <= value <= 1.0
+        elif value != 0.0:                                  # +-0.997^k, k >= 1 plies before the end
             k = math.log(abs(float(value))) / math.log(0.997)
             assert k > 0.5 and abs(k - round(k)) < 1e-2, value
         assert F.format_target(n, st, mv, pol, value, ube) == line
     moves_total = 0
-    for line in replays.decode().splitlines():
+    for line in (replays or b"").decode().splitlines():
         start, moves = F.parse_replay(line, n, 4)
         s = O.TzState.from_buffer_copy(np.array([start]).tobytes())
         for m in moves:
@@ -207,37 +209,45 @@ def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
     _check_lines(oracle, n, targets, replays, "gumbel")
 
 
-def test_closed_loop_of_the_two_cpp_programs_over_ot_files(oracle, tmp_path):
+def test_closed_loop_of_the_three_cpp_programs_over_ot_files(oracle, tmp_path):
     """learn_cli (tz_learn_run with its own save points) writes model_0000000.ot, model_<pre>.ot and
-    model_latest.ot as LibTorch archives; selfplay_cli (started from Net::new) reloads model_latest.ot while it plays and feeds
-    learn's buffer through targets-selfplay.txt — the reference's three-file protocol between two C++ processes, no Python,
-    no torch, no LibTorch in either.  The archives are then read back by LibTorch itself (torch.jit.load)."""
+    model_latest.ot as LibTorch archives; selfplay_cli (started from Net::new) and reanalyze_cli reload model_latest.ot while they
+    run, selfplay feeds learn through targets-selfplay.txt and reanalyze through replays.txt, reanalyze feeds learn through
+    targets-reanalyze.txt (learn switches to half-and-half batches at --steps-before-reanalyze) - the reference's deployment
+    (README.md:130) as three C++ processes on one directory and one GPU, no Python, no torch, no LibTorch in any of them.  The
+    archives are then read back by LibTorch itself (torch.jit.load)."""
     import subprocess
     import time
 
     require_gpu()
     from takzero_amd import ot
 
-    learn, selfplay = _build_example(tmp_path, "learn_cli"), _build_example(tmp_path, "selfplay_cli")
+    learn, selfplay, reanalyze = (_build_example(tmp_path, name) for name in ("learn_cli", "selfplay_cli", "reanalyze_cli"))
     d, n = str(tmp_path / "run"), 4
     os.makedirs(d)
     common = ["--arch", "100", "--n", str(n), "--blocks", "1"]
     lp = subprocess.Popen([learn, "--directory", d, "--batch", "64", "--steps", "90", "--seed", "5", "--pre-training-steps", "20",
-                           "--initial-targets", "2000", "--min-selfplay", "300", "--steps-per-save", "30", "--steps-per-checkpoint", "60",
-                           "--steps-before-reanalyze", "100000", "--read-interval", "0.2", "--sleep", "0.2", "--wait-limit", "240"] + common,
-                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                           "--initial-targets", "2000", "--min-selfplay", "300", "--min-reanalyze", "128", "--steps-per-save", "30",
+                           "--steps-per-checkpoint", "60", "--steps-before-reanalyze", "60", "--read-interval", "0.2", "--sleep", "0.2",
+                           "--wait-limit", "240"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     t0 = time.time()
     while not os.path.exists(os.path.join(d, "buffer_lengths.txt")) and time.time() - t0 < 120 and lp.poll() is None:
         time.sleep(0.1)
     assert os.path.exists(os.path.join(d, "buffer_lengths.txt")), lp.communicate()[1][-1500:]
+    rp = subprocess.Popen([reanalyze, "--directory", d, "--games", "64", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel",
+                           "--iterations", "12", "--min-positions", "500", "--wait-limit", "120", "--seed", "4"] + common,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     sp = subprocess.run([selfplay, "--directory", d, "--games", "64", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel",
                          "--moves", "150", "--wait-limit", "60", "--seed", "9"] + common, capture_output=True, text=True, timeout=600)
+    rout, rerr = rp.communicate(timeout=600)
     lout, lerr = lp.communicate(timeout=600)
     assert sp.returncode == 0, (sp.stdout, sp.stderr[-1500:])
+    assert rp.returncode == 0, (rout, rerr[-1500:])
     assert lp.returncode == 0, (lout, lerr[-1500:])
-    lf, sf = _fields(lout), _fields(sp.stdout)
+    lf, sf, rf = _fields(lout), _fields(sp.stdout), _fields(rout)
     assert lf["model_steps"] == "110" and lf["starting_steps"] == "20" and lf["rc"] == "0"
     assert int(sf["model_reloads"]) >= 2 and sf["moves"] == "150"     # the initial model_latest.ot and at least one save point
+    assert rf["rc"] == "0" and int(rf["model_reloads"]) >= 1 and int(rf["simulations"]) >= 12 * 64 * 16
     names = sorted(f for f in os.listdir(d) if f.endswith(".ot"))
     assert names == ["model_0000000.ot", "model_0000020.ot", "model_0000060.ot", "model_latest.ot"], names
     assert not [f for f in os.listdir(d) if f.endswith(".part")]
@@ -248,6 +258,9 @@ def test_closed_loop_of_the_two_cpp_programs_over_ot_files(oracle, tmp_path):
     targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
     replays = open(os.path.join(d, "replays.txt"), "rb").read()
     _check_lines(oracle, n, targets, replays, "gumbel")
+    re_targets = open(os.path.join(d, "targets-reanalyze.txt"), "rb").read()
+    assert re_targets.count(b"\n") == 12 * 64
+    _check_lines(oracle, n, re_targets, None, "gumbel", game_values=False)
 
 
 def test_two_shards_of_the_cpp_program_hand_over_to_rank_0(oracle, tmp_path):
