@@ -17,7 +17,9 @@ packed target records and replay lines — an all-gather of counts, then of the 
 on the path; by default through the library's own RCCL communicator (tz_comm_*, ncclAllGather on the shard's GPU;
 TZ_BENCH_EXCHANGE=torch runs it through torch.distributed instead).  The JSON line names the backend, the world size
 and the transport; if RCCL cannot form the ring the run ends with a non-zero exit code (no silent fallback;
-TZ_BENCH_BACKEND=gloo is an explicit rehearsal switch).
+TZ_BENCH_BACKEND=gloo is an explicit rehearsal switch).  If the ring is up but the library's own communicator does not come
+up on some rank, all ranks agree (one all-reduce) to hand the targets over through the process group instead - the same RCCL
+ring - and the line's `exchange` says so with every rank's error; TZ_BENCH_EXCHANGE=native makes that an exit code 4 too.
 
 Prints ONE JSON line (rank 0).  `value` = MCTS simulations/s summed over all ranks.
 """
@@ -220,7 +222,7 @@ def main():
     dev = "cuda:%d" % local_rank if backend == "nccl" else "cpu"
     # the hand-over of the finished targets between the shards
     exchange = os.environ.get("TZ_BENCH_EXCHANGE", "native" if args.driver == "native" else "torch")
-    comm = None
+    comm, native_error = None, None
     if dist is not None and exchange == "native":
         from takzero_amd import comm as CM
 
@@ -242,11 +244,25 @@ def main():
             comm.barrier()
             probe = comm.all_gather(b"rank %d" % rank)    # fail here, not in the timed region, if the ring does not carry data
             assert probe == [b"rank %d" % r for r in range(world)], probe
-            sp.set_comm(comm, writer_rank=-1)   # every rank ends up with all the lines, as `learn` on any rank would need
         except Exception as e:
-            sys.stderr.write("rank %d: the native exchange (tz_comm over %s) failed: %r\n" % (rank, backend, e))
+            native_error = repr(e)
+            sys.stderr.write("rank %d: the native exchange (tz_comm over %s) failed: %s\n" % (rank, backend, native_error))
             sys.stderr.flush()
-            os._exit(4)
+        # every rank takes the same road: if the library's communicator did not come up on any one of them, all of them hand the
+        # targets over through the process group that is already up (same RCCL ring, torch's calls), and the line says so
+        ok = torch.tensor([0 if native_error else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            sp.set_comm(comm, writer_rank=-1)   # every rank ends up with all the lines, as `learn` on any rank would need
+        else:
+            if os.environ.get("TZ_BENCH_EXCHANGE") == "native":   # asked for by name: no other road
+                os._exit(4)
+            errors = [None] * world
+            dist.all_gather_object(errors, native_error)
+            native_error = "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errors) if e)
+            if comm is not None:
+                comm.close()
+            comm = None
 
     def barrier():
         mcts.sync()
@@ -303,7 +319,8 @@ def main():
             "world": world,
             "backend": (backend if dist is not None else "none (single process)"),
             "exchange": ((dict(comm.info(), api="tz_comm (csrc/tz_comm.cpp)") if comm is not None
-                          else {"transport": "torch.distributed " + backend}) if dist is not None else None),
+                          else dict({"transport": "torch.distributed " + backend},
+                                    **({"native_exchange_error": native_error} if native_error else {}))) if dist is not None else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt_max / max(1, args.steps),

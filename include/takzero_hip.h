@@ -104,6 +104,11 @@ typedef struct tz_search tz_search; /* opaque: BatchedMCTS<B, Game<N,HALF_KOMI>>
 #define TZ_PREC_F16X2 3 /* split precision: every operand a hi/lo pair of halves (22-bit significand), three fp16 MFMAs
                           per product with fp32 accumulate: logits within 1e-3 absolute of the fp32 LibTorch graph at
                           trained logit scale (|logit| ~ 10), the north star's tolerance; ~3x the MFMA work */
+#define TZ_PREC_F16C8 4 /* fp16 products with FP8 corrections: the main product wh*xh as in TZ_PREC_F16, the two correction
+                          products wl*xh + wh*xl of the split form on OCP FP8 (E4M3) copies of the operands through
+                          v_mfma_f32_16x16x128_f8f6f4 (twice the fp16 rate): a correction only has to be good to a few
+                          bits.  Logits within 1e-3 absolute at trained logit scale like TZ_PREC_F16X2 (about 30x
+                          closer to fp32 than TZ_PREC_F16), ~2x the MFMA time of TZ_PREC_F16 instead of 3x */
 
 /* built-in agents for tz_search_create (takzero/src/search/agent.rs:16-87) */
 #define TZ_AGENT_NET 0

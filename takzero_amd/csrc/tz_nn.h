@@ -11,6 +11,8 @@ struct ConvW {
     int taps = 0, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
     uint16_t* w_mfma = nullptr;  // bf16 / fp16 bits, fragment order [tap][kc][ct][lane][8]
     uint16_t* w_lo = nullptr;    // TZ_PREC_F16X2: fp16((w - hi) * 2^11) in the same order
+    unsigned char* w8 = nullptr; // TZ_PREC_F16C8: FP8 E4M3 fragments [tap][m = cin/128][ct][term: lo, hi][lane][32] of (w - hi) * 2^11 * s and hi * s
+    float c8_scale = 0.0f;       //   what the correction accumulator is multiplied by: 2^-11 / (s * C8_SX), s = the layer's power of two
     float* w_f32 = nullptr;      // [tap][cout][cin]
     float* bias = nullptr;       // [cout_pad]  (BatchNorm folded in)
 };
@@ -25,6 +27,8 @@ struct tz_net {
     std::vector<ConvW> res;  // 2 per block
     uint16_t* tower_w = nullptr;  // all residual-tower layers back to back (fused tower kernel)
     uint16_t* tower_w_lo = nullptr;  // TZ_PREC_F16X2: their lo halves
+    unsigned char* tower_w8 = nullptr;  // TZ_PREC_F16C8: their FP8 fragments
+    float* c8_scales = nullptr;         // TZ_PREC_F16C8: [2*blocks + 1] correction scales of the tower layers, then of the policy conv
     float* tower_bias = nullptr;  // [2*blocks][256]
     float* heads = nullptr;  // [value conv w 256, ube conv w 256, value lin nn, ube lin nn, bv, bu, lbv, lbu]
     ConvW rnd[2][3];         // [learning, target][input, hidden, final]  (fp32 path)

@@ -15,6 +15,8 @@
 //     (net6_simhash.rs:208-256) with the 2^32-bit set resident in HBM.
 //   * an fp32 validation path (TZ_PREC_F32) with plain FMA kernels for the 1e-3 logit gate.
 #include "tz_nn.h"
+#include "tz_fp8.h"
+#include <type_traits>
 #include "tz_ot.h"
 
 #include <algorithm>
@@ -912,6 +914,11 @@ struct NetArgs {
     const uint16_t* w_in_lo;
     const uint16_t* w_lo;
     const uint16_t* w_pol_lo;
+    // FP8 corrections (SP = 2): FP8 fragments of the tower and of the policy conv, and what their correction accumulators are
+    // multiplied by ([nlayers] tower layers, then the policy conv)
+    const unsigned char* w8;
+    const unsigned char* w_pol8;
+    const float* c8_scales;
     unsigned long long* dbg;   // diagnostic builds (ABL & 8): [workgroup][4] = memtime, memrealtime before / after the tower
 };
 
@@ -1427,6 +1434,242 @@ __device__ __forceinline__ void k_loop_split(const unsigned char* lds, const int
     one_tap(IntC<8>{});
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// FP16 products with FP8 corrections (TZ_PREC_F16C8).  The split form above spends two of its three MFMAs on the correction
+// wl*xh + wh*xl, a quantity 2^-11 of the product that only has to be right to a few bits for the sum to be right to 15.  Here
+// those two products run on OCP FP8 (E4M3) copies of the four operands through v_mfma_f32_16x16x128_f8f6f4 - 128 input
+// channels per instruction at twice the fp16 rate (32 cycles for 4x the K of the 16-cycle 16x16x32, tools/mfma_f8_probe.hip)
+// - so a tap of 256 channels costs 8 fp16 + 4 FP8 MFMAs = 256 cycles per (row tile, 16 outputs) instead of 24 x 16 = 384.
+// Image: planes 0..7 hi (fp16, as TZ_PREC_F16), 8..11 FP8 of hi * C8_SX, 12..15 FP8 of (x - hi) * 2^11 * C8_SX, 16..19 FP8 of
+// what that second byte still misses (* 16): only the residual connection reads it (the block input is carried to 19 bits;
+// carried at 15 the logits lose a factor 2, tools/fp8_correction_study.py).  An FP8 plane is [row][64 channels] with the
+// same 16-B piece rotation as an fp16 plane, so a lane's tap-table address serves all of them: its 32 operand bytes of
+// K-half m are piece q of planes 2m and 2m + 1.  Steps of a tap: fp16 chunks 0..3, FP8 half 0, chunks 4..7, FP8 half 1.
+constexpr float C8_SX = 4.0f;                       // activations times 4: E4M3 saturates at 112, keeps 4 bits down to 2^-8
+constexpr float C8_LO = 2048.0f * C8_SX;            // scale of the lo byte
+constexpr float C8_LO_INV = 1.0f / C8_LO;
+constexpr float C8_RS = 16.0f, C8_RS_INV = 1.0f / 16.0f;   // the remainder byte, relative to the lo byte
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_f8(i32x8 a, i32x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);   // both scales 0: the unscaled instruction
+}
+__device__ __forceinline__ i32x8 lds_f8_frag(const unsigned char* lds, int addr, int plane_bytes) {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(lds + addr);
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(lds + addr + plane_bytes);
+    return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// four values -> four E4M3 bytes (clamped: the instruction turns overflow into NaN)
+__device__ __forceinline__ int pack_e4m3(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.0f, 448.0f), __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.0f, 448.0f), __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f), w, true);
+    return w;
+}
+__device__ __forceinline__ float e4m3_byte(int w, int k) {
+    return k == 0 ? __builtin_amdgcn_cvt_f32_fp8(w, 0) : k == 1 ? __builtin_amdgcn_cvt_f32_fp8(w, 1) : k == 2 ? __builtin_amdgcn_cvt_f32_fp8(w, 2)
+                                                                                                        : __builtin_amdgcn_cvt_f32_fp8(w, 3);
+}
+// an activation's stored parts: hi (fp16) and the FP8 words of 4 channels; want_r: also the remainder word.  v is post-ReLU and
+// at most 65504.  The scaled conversions divide by the power of two in `scale` and do not saturate (overflow is NaN,
+// tools/cvt_scale_probe.hip), so the hi copy is capped at 112 = 448 / C8_SX and the lo part at +-448 / C8_LO first.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void c8_parts(const f32x4& v, f16x4& hi, int& h8, int& l8, int& r8, bool want_r) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        hi[k] = (_Float16)v[k];
+        t[k] = __builtin_amdgcn_fmed3f(v[k] - (float)hi[k], -448.0f / C8_LO, 448.0f / C8_LO);
+    }
+    const f16x2 cap = {(_Float16)(448.0f / C8_SX), (_Float16)(448.0f / C8_SX)};
+    s16x2 w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, __builtin_elementwise_min(f16x2{hi[0], hi[1]}, cap), 1.0f / C8_SX, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w, __builtin_elementwise_min(f16x2{hi[2], hi[3]}, cap), 1.0f / C8_SX, true);
+    h8 = __builtin_bit_cast(int, w);
+    s16x2 x = {0, 0};
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(x, t[0], t[1], C8_LO_INV, false);
+    x = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(x, t[2], t[3], C8_LO_INV, true);
+    l8 = __builtin_bit_cast(int, x);
+    r8 = 0;
+    if (want_r) {   // what the lo byte misses, 16 times finer: |.| <= 16 * half an E4M3 step <= 256, no cap needed
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = __builtin_fmaf(e4m3_byte(l8, k), -C8_LO_INV, t[k]);
+        s16x2 y = {0, 0};
+        y = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(y, r[0], r[1], C8_LO_INV * C8_RS_INV, false);
+        y = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(y, r[2], r[3], C8_LO_INV * C8_RS_INV, true);
+        r8 = __builtin_bit_cast(int, y);
+    }
+}
+__device__ __forceinline__ float c8_value(_Float16 hi, int l8, int r8, int k) {
+    return (float)hi + (e4m3_byte(l8, k) + e4m3_byte(r8, k) * C8_RS_INV) * C8_LO_INV;
+}
+
+// One tap is a stream of 12 x NA items (NA = row tiles the tap does not skip): fp16 chunk kc of tile rt (one ds_read_b128, RNX
+// fp16 MFMAs) or FP8 term of half m of tile rt (two ds_read_b128, RNX FP8 MFMAs; term 0 = wl8 * hi bytes, term 1 = wh8 * lo
+// bytes).  The operands run D items ahead of the MFMAs through a ring of D 32-byte slots, across tap boundaries (the next
+// tap's fragment addresses are read from the tap table two chunks before it starts); consecutive MFMAs never share an
+// accumulator (all tiles of one chunk or term, then the next).
+template <int NB, int P, bool PERM, int RNX, int PLANE, typename TapT, typename WL, typename WL8>
+__device__ __forceinline__ void k_loop_c8(const unsigned char* lds, const TapT* tap_table, int lane,
+                                          f32x4 (&accm)[RowMap<NB, P, PERM>::RT][RNX], f32x4 (&accc)[RowMap<NB, P, PERM>::RT][RNX], WL wl, WL8 wl8) {
+    typedef Elem<_Float16> E;
+    typedef f16x8 ex8;
+    typedef RowMap<NB, P, PERM> RM;
+    constexpr int TAPS = 9, RT = RM::RT, D = 4;
+    static_assert(7 * PLANE < 65536, "plane offsets of a ring load must fit a ds_read immediate");
+    ex8 bq[4][RNX];
+#pragma unroll
+    for (int j = 0; j < RNX; j++) {
+        bq[0][j] = wl(0, 0, j);
+        bq[1][j] = wl(0, 1, j);
+    }
+    i32x8 b8[RNX][2];      // FP8 weight fragments of the coming half: [j][term: lo, hi]
+    i32x8 rg[D];
+    int abase[RT], abase8[RT], abn[RT];   // fragment addresses of the tap: fp16 planes, FP8 planes; of the next tap
+    // item u of a tap with mask M: segment, tile, byte offset of its operand from the tile's fragment address
+    // (fp16 planes from abase, FP8 planes from abase + 8 planes: both offsets stay below 7 planes)
+    auto load_item = [&](auto mask_c, auto u_c, int (&ab)[RT], int (&ab8)[RT], i32x8& dst) {
+        constexpr unsigned M = decltype(mask_c)::value;
+        constexpr int u = decltype(u_c)::value;
+        constexpr int NA = __builtin_popcount(M);
+        constexpr int seg = u < 4 * NA ? 0 : u < 6 * NA ? 1 : u < 10 * NA ? 2 : 3;
+        constexpr int v = u - (seg == 0 ? 0 : seg == 1 ? 4 * NA : seg == 2 ? 6 * NA : 10 * NA);
+        constexpr int ti = v % NA, grp = v / NA;
+        int rt = 0;
+        {
+            int seen = 0;
+#pragma unroll
+            for (int r = 0; r < RT; r++)
+                if ((M >> r) & 1) {
+                    if (seen == ti) rt = r;
+                    seen++;
+                }
+        }
+        if constexpr (seg == 0 || seg == 2) {
+            const i32x4 x = *reinterpret_cast<const i32x4*>(lds + ab[rt] + ((seg == 2 ? 4 : 0) + grp) * PLANE);
+            dst[0] = x[0];
+            dst[1] = x[1];
+            dst[2] = x[2];
+            dst[3] = x[3];
+        } else {
+            constexpr int m = seg == 1 ? 0 : 1;
+            dst = lds_f8_frag(lds, ab8[rt] + (2 * m + 4 * grp) * PLANE, PLANE);
+        }
+    };
+    {
+        constexpr unsigned M0 = RM::tap_tile_mask(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+            if ((M0 >> rt) & 1) {
+                abase[rt] = tap_table[rt * 64 + lane];
+                abase8[rt] = abase[rt] + 8 * PLANE;
+            }
+        load_item(IntC<(int)M0>{}, IntC<0>{}, abase, abase8, rg[0]);
+        load_item(IntC<(int)M0>{}, IntC<1>{}, abase, abase8, rg[1]);
+        load_item(IntC<(int)M0>{}, IntC<2>{}, abase, abase8, rg[2]);
+        load_item(IntC<(int)M0>{}, IntC<3>{}, abase, abase8, rg[3]);
+    }
+    auto one_tap = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr unsigned NOW = RM::tap_tile_mask(tap);
+        constexpr unsigned NEXT = tap + 1 < TAPS ? RM::tap_tile_mask(tap + 1 < TAPS ? tap + 1 : tap) : 0u;
+        constexpr int NA = __builtin_popcount(NOW), NI = 12 * NA;
+        static_assert(NA >= 1 && 12 * __builtin_popcount(NEXT ? NEXT : 1u) >= D, "ring depth");
+        auto item = [&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            constexpr int seg = u < 4 * NA ? 0 : u < 6 * NA ? 1 : u < 10 * NA ? 2 : 3;
+            constexpr int v = u - (seg == 0 ? 0 : seg == 1 ? 4 * NA : seg == 2 ? 6 * NA : 10 * NA);
+            constexpr int ti = v % NA, grp = v / NA;
+            int rt = 0;
+            {
+                int seen = 0;
+#pragma unroll
+                for (int r = 0; r < RT; r++)
+                    if ((NOW >> r) & 1) {
+                        if (seen == ti) rt = r;
+                        seen++;
+                    }
+            }
+            if constexpr ((seg == 0 || seg == 2) && ti == 0) {   // a new fp16 chunk starts: weights two chunks ahead
+                constexpr int kc = (seg == 2 ? 4 : 0) + grp;
+                if (kc + 2 < 8) {
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap, kc + 2, j);
+                } else if (tap + 1 < TAPS) {
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) bq[(kc + 2) & 3][j] = wl(tap + 1, kc + 2 - 8, j);
+                }
+                if (kc == 1 || kc == 5) {   // the FP8 fragments of the half that follows chunk 3 / 7
+#pragma unroll
+                    for (int j = 0; j < RNX; j++) {
+                        b8[j][0] = wl8(tap, kc >> 2, j, 0);
+                        b8[j][1] = wl8(tap, kc >> 2, j, 1);
+                    }
+                }
+                if (kc == 6) {   // the next tap's fragment addresses
+#pragma unroll
+                    for (int r = 0; r < RT; r++)
+                        if ((NEXT >> r) & 1) abn[r] = tap_table[((tap + 1) * RT + r) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (seg == 0 || seg == 2) {
+                constexpr int kc = (seg == 2 ? 4 : 0) + grp;
+                const i32x4 x = i32x4{rg[u % D][0], rg[u % D][1], rg[u % D][2], rg[u % D][3]};
+                const ex8 av = __builtin_bit_cast(ex8, x);
+#pragma unroll
+                for (int j = 0; j < RNX; j++) accm[rt][j] = E::mfma(bq[kc & 3][j], av, accm[rt][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < RNX; j++) accc[rt][j] = mfma_f8(b8[j][grp], rg[u % D], accc[rt][j]);
+            }
+            // refill the slot with the item D ahead: of this tap, or of the next
+            if constexpr (u + D < NI) {
+                load_item(IntC<(int)NOW>{}, IntC<u + D>{}, abase, abase8, rg[u % D]);
+                constexpr int un = u + D;
+                constexpr bool f8n = (un >= 4 * NA && un < 6 * NA) || un >= 10 * NA;
+                __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, f8n ? 2 : 1, 0);
+            } else if constexpr (NEXT != 0u) {
+                load_item(IntC<(int)NEXT>{}, IntC<u + D - NI>{}, abn, abn, rg[u % D]);   // an fp16 item: the FP8 base is not read
+                __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        // the items in order (at most 12 x 7: the index sequence is spelled out through a recursive lambda)
+        auto run = [&](auto self, auto u_c) -> void {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (u < NI) {
+                item(u_c);
+                self(self, IntC<u + 1>{});
+            }
+        };
+        run(run, IntC<0>{});
+        if constexpr (NEXT != 0u) {
+#pragma unroll
+            for (int r = 0; r < RT; r++)
+                if ((NEXT >> r) & 1) {
+                    abase[r] = abn[r];
+                    abase8[r] = abn[r] + 8 * PLANE;
+                    asm volatile("" : "+v"(abase8[r]));   // keep it a register: the plane offsets then fold into the ds_read immediates
+                }
+        }
+    };
+    one_tap(IntC<0>{});
+    one_tap(IntC<1>{});
+    one_tap(IntC<2>{});
+    one_tap(IntC<3>{});
+    one_tap(IntC<4>{});
+    one_tap(IntC<5>{});
+    one_tap(IntC<6>{});
+    one_tap(IntC<7>{});
+    one_tap(IntC<8>{});
+}
+
 // hi / lo halves of an fp32 value (both saturating)
 __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo) {
     hi = Elem<_Float16>::cvt(v);
@@ -1434,6 +1677,8 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 }
 
 // SP = 1: split precision (k_loop_split): 16 image planes (hi 0..7, lo 8..15), two accumulator sets, hi / lo weight buffers.
+// SP = 2: fp16 products with FP8 corrections (k_loop_c8): 20 image planes (hi 0..7, FP8 hi 8..11, FP8 lo 12..15, FP8 remainder
+//         16..19), 16-bit tap table entries; the first conv runs the split form on planes 8.. as fp16 lo halves of its input.
 // ABL: ablation bits of k_loop_256_skip for the tower (diagnostic builds); bit 8 = stamp s_memtime / s_memrealtime around the tower
 // into a.dbg (the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back item 6) - no output depends on the stamps.
 // TT = 1: compact tap table + ring loop (k_loop_256_ring): the form for 18 row tiles (6x6, 8 boards); needs PERM and 16 % P == 0.
@@ -1446,11 +1691,13 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     typedef RowMap<NB, P, PERM> RM;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
-    constexpr int NPL = SP ? 16 : 8, LO = 8 * PLANE;   // image planes; byte offset of the lo half of a plane
+    constexpr int NPL = SP == 2 ? 20 : SP ? 16 : 8, LO = 8 * PLANE;   // image planes; byte offset of the lo half of a plane
+    typedef typename std::conditional<SP == 2, uint16_t, int>::type tap_t;   // a fragment address inside a plane fits 16 bits
+    static_assert(SP != 2 || PLANE < 65536, "16-bit tap table");
     constexpr int LAYER_FRAGS = TAPS * 8 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* hscratch = reinterpret_cast<float*>(lds + NPL * PLANE);  // [2][RT*16] head pre-activations
-    int* tap_table = reinterpret_cast<int*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes], TT = 1: [TAPS][RT][PPT]
+    tap_t* tap_table = reinterpret_cast<tap_t*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes], TT = 1: [TAPS][RT][PPT]
     static_assert(!TT || (PERM && !SP && 16 % P == 0 && P >= 8), "compact tap table: square-major rows with whole 8-row runs per square");
     const int count = a.count_dev ? *a.count_dev : a.count_host;
     const int pos0 = blockIdx.x * P;
@@ -1527,7 +1774,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             if constexpr (PERM) tap_bases_map<NB, P, true, LAYOUT>(tap, lr, q, ZROW, tb);
             else tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = tb[rt];
+            for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = (tap_t)tb[rt];
         }
     }
     auto ta = [&](int tap, int rt) -> int {   // the lane's fragment base address of row tile rt under `tap`
@@ -1537,6 +1784,21 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     int obase[RN];
 #pragma unroll
     for (int j = 0; j < RN; j++) obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
+    // SP = 2: where the lane's four channels (16 * (2 wave + j) + 4 q ..) sit in the FP8 hi plane: plane 8 + wave / 2 of 64 channels,
+    // piece 2 (wave & 1) + j, byte 4 q; the lo and remainder planes are 4 and 8 planes further
+    int obase8[RN];
+#pragma unroll
+    for (int j = 0; j < RN; j++) obase8[j] = (8 + (wave >> 1)) * PLANE + lr * LDS_ROWB + lds_piece(lr, (wave & 1) * 2 + j) + q * 4;
+    // stores one output tile's values (post-ReLU) in the parts the image of this SP holds
+    auto store_c8 = [&](const f32x4& v, int j, int rt, bool block_output) {
+        f16x4 hi;
+        int h8, l8, r8;
+        c8_parts(v, hi, h8, l8, r8, block_output);
+        *reinterpret_cast<f16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = hi;
+        *reinterpret_cast<int*>(lds + obase8[j] + rt * 16 * LDS_ROWB) = h8;
+        *reinterpret_cast<int*>(lds + obase8[j] + 4 * PLANE + rt * 16 * LDS_ROWB) = l8;
+        if (block_output) *reinterpret_cast<int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB) = r8;
+    };
 
     f32x4 acc[RT][RN];
     f32x4 accc[SP ? RT : 1][RN];   // split precision: the correction accumulator (wl*xh + wh*xl), scaled by 2^-11 per layer
@@ -1652,6 +1914,15 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         for (int j = 0; j < RN; j++)
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
+                if constexpr (SP == 2) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        v[k] = __builtin_amdgcn_fmed3f(acc[rt][j][k] + accc[rt][j][k] * SPLIT_INV, 0.0f, 65504.0f);
+                    }
+                    store_c8(v, j, rt, true);
+                    continue;
+                }
                 ex4 pk, pl;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1671,7 +1942,9 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     }
     // ---- residual tower
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? a.w_lo : a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP == 1 ? a.w_lo : a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(SP == 2 ? a.w8 : reinterpret_cast<const unsigned char*>(a.w)), 0,
+                                                                            a.nlayers * TAPS * 2 * 16 * 2 * 2048, 0x00020000);
     if constexpr (ABL & 8) {
         if (tid == 0 && a.dbg) {
             a.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -1694,7 +1967,19 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 for (int rt = 0; rt < RT; rt++) accc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
-        if constexpr (SP) {
+        if constexpr (SP == 2) {
+            auto wl = [&](int tap, int kc, int j) -> ex8 {
+                const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
+                return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
+            };
+            auto wl8 = [&](int tap, int m, int j, int term) -> i32x8 {
+                const int frag = ((layer * TAPS * 2 + tap * 2 + m) * 16 + (ct0 + j)) * 2 + term;   // 2 KB each
+                const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc8, lane * 32, frag * 2048, 0));
+                const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc8, lane * 32 + 16, frag * 2048, 0));
+                return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            k_loop_c8<NB, P, PERM, RN, PLANE>(lds, tap_table, lane, acc, accc, wl, wl8);
+        } else if constexpr (SP) {
             auto wl2 = [&](int tap, int kc, int j, int part) -> ex8 {
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(part ? wrsrc_lo : wrsrc, lane16, frag * 1024, 0));
@@ -1719,7 +2004,22 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             for (int rt = 0; rt < RT; rt++) {
                 ex4* slot = reinterpret_cast<ex4*>(lds + obase[j] + rt * 16 * LDS_ROWB);
                 ex4 pk;
-                if constexpr (SP) {
+                if constexpr (SP == 2) {
+                    const float cs = a.c8_scales[layer];
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        v[k] = __builtin_amdgcn_fmed3f(acc[rt][j][k] + accc[rt][j][k] * cs, 0.0f, 65504.0f);
+                    }
+                    if (to_second) {   // the block input, carried to 19 bits, starts the second conv's accumulator
+                        const f16x4 xh = *reinterpret_cast<const f16x4*>(slot);
+                        const int xl8 = *reinterpret_cast<const int*>(lds + obase8[j] + 4 * PLANE + rt * 16 * LDS_ROWB);
+                        const int xr8 = *reinterpret_cast<const int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) acc[rt][j][k] = c8_value(xh[k], xl8, xr8, k) + b4[k];
+                    }
+                    store_c8(v, j, rt, !to_second);
+                } else if constexpr (SP) {
                     ex4* slot_lo = reinterpret_cast<ex4*>(lds + LO + obase[j] + rt * 16 * LDS_ROWB);
                     ex4 pl;
 #pragma unroll
@@ -1784,7 +2084,12 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 float xf[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) xf[k] = (float)xv[k];
-                if constexpr (SP) {
+                if constexpr (SP == 2) {   // channels 4 lane ..: FP8 plane lane / 16, piece (lane & 15) / 4, byte 4 (lane & 3)
+                    const int h8addr = (12 + (lane >> 4)) * PLANE + row * LDS_ROWB + lds_piece(row, (lane & 15) >> 2) + (lane & 3) * 4;
+                    const int xl8 = *reinterpret_cast<const int*>(lds + h8addr), xr8 = *reinterpret_cast<const int*>(lds + h8addr + 4 * PLANE);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xf[k] = c8_value(xv[k], xl8, xr8, k);
+                } else if constexpr (SP) {
                     const ex4 xl = *reinterpret_cast<const ex4*>(lds + LO + haddr);
 #pragma unroll
                     for (int k = 0; k < 4; k++) xf[k] += (float)xl[k] * SPLIT_INV;
@@ -1848,7 +2153,32 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) pacc[rt][j] = b4;
         }
-        if constexpr (SP) {
+        if constexpr (SP == 2) {
+            const __amdgpu_buffer_rsrc_t rs8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.w_pol8), 0, TAPS * 2 * 8 * RNP * 2 * 2048, 0x00020000);
+            f32x4 paccc[RT][RNP];
+#pragma unroll
+            for (int j = 0; j < RNP; j++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) paccc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto wlp = [&](int tap, int kc, int j) -> ex8 {
+                const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
+                return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
+            };
+            auto wlp8 = [&](int tap, int m, int j, int term) -> i32x8 {
+                const int frag = ((tap * 2 + m) * (8 * RNP) + (ctp + j)) * 2 + term;
+                const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs8, lane * 32, frag * 2048, 0));
+                const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs8, lane * 32 + 16, frag * 2048, 0));
+                return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            k_loop_c8<NB, P, PERM, RNP, PLANE>(lds, tap_table, lane, pacc, paccc, wlp, wlp8);
+            const float cs = a.c8_scales[a.nlayers];
+#pragma unroll
+            for (int j = 0; j < RNP; j++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pacc[rt][j][k] += paccc[rt][j][k] * cs;
+        } else if constexpr (SP) {
             const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_pol_lo), 0, TAPS * 8 * 8 * RNP * 1024, 0x00020000);
             f32x4 paccc[RT][RNP];
 #pragma unroll
@@ -2173,7 +2503,9 @@ uint16_t f2h(float f) {  // IEEE binary16, round to nearest even (host clang has
 
 // TZ_PREC_F16X2 runs the fp16 kernels everywhere (RND side networks included) except in the fused trunk + heads launch,
 // where every operand is a hi / lo pair of halves (k_loop_split)
-inline bool prec_is_f16(int precision) { return precision == TZ_PREC_F16 || precision == TZ_PREC_F16X2; }
+// TZ_PREC_F16C8 likewise; its fused launch takes the correction products through FP8 copies of the operands (k_loop_c8)
+inline bool prec_is_f16(int precision) { return precision == TZ_PREC_F16 || precision == TZ_PREC_F16X2 || precision == TZ_PREC_F16C8; }
+inline bool prec_is_split(int precision) { return precision == TZ_PREC_F16X2 || precision == TZ_PREC_F16C8; }
 
 struct Tensor {
     std::vector<uint32_t> dims;
@@ -2218,7 +2550,7 @@ int upload(const std::vector<T>& h, T** dev) {
 // in_perm (optional): source input index for each of my input indices.
 int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const std::vector<float>& w,
                 const std::vector<float>& scale, const std::vector<float>& bias, const std::vector<int>* in_perm,
-                ConvW* L, bool with_lo = false) {
+                ConvW* L, bool with_lo = false, bool with_c8 = false) {
     L->taps = taps;
     L->cin = cin;
     L->cin_pad = (cin + 31) / 32 * 32;
@@ -2258,6 +2590,38 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
                         }
                     }
         if (with_lo && (rc = upload(plo, &L->w_lo))) return rc;
+        if (with_c8) {
+            // FP8 fragments of the two correction products (k_loop_c8).  One 16x16x128 MFMA covers 128 input channels: lane
+            // (row = lane & 15, q = lane >> 4) holds 32 of them, bytes 0..15 = channels 128m + 16q .. and bytes 16..31 =
+            // channels 128m + 64 + 16q .. (the two FP8 image planes of the half, piece q of each).  s = the power of two that
+            // brings the layer's largest |w| to [128, 256): E4M3 then keeps 4 significant bits down to 2^-13 of it.
+            if (L->cin_pad % 128) return tz_fail(TZ_EINVAL, "weights: TZ_PREC_F16C8 needs input channels in multiples of 128");
+            float wmax = 0.0f;
+            for (int co = 0; co < cout; co++)
+                for (int ci = 0; ci < cin; ci++)
+                    for (int t = 0; t < taps; t++) wmax = std::max(wmax, fabsf(W(co, ci, t)));
+            const float sw = wmax > 0.0f ? exp2f(floorf(log2f(256.0f / wmax))) : 1.0f;
+            L->c8_scale = 1.0f / (2048.0f * sw * C8_SX);
+            const int m_total = L->cin_pad / 128;
+            std::vector<unsigned char> p8((size_t)taps * m_total * ct_total * 2 * 64 * 32, 0);
+            for (int t = 0; t < taps; t++)
+                for (int mh = 0; mh < m_total; mh++)
+                    for (int ct = 0; ct < ct_total; ct++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int co = ct * 16 + (lane & 15), q = lane >> 4;
+                            if (co >= cout) continue;
+                            for (int i = 0; i < 32; i++) {
+                                const int ci = 128 * mh + 64 * (i >> 4) + 16 * q + (i & 15);
+                                if (ci >= cin) continue;
+                                const float wv = W(co, ci, t);
+                                const _Float16 hi = (_Float16)wv;
+                                const size_t at = (((((size_t)t * m_total + mh) * ct_total + ct) * 2) * 64 + lane) * 32 + i;
+                                p8[at] = tz_f32_to_e4m3((wv - (float)hi) * 2048.0f * sw);
+                                p8[at + 64 * 32] = tz_f32_to_e4m3((float)hi * sw);
+                            }
+                        }
+            if ((rc = upload(p8, &L->w8))) return rc;
+        }
         return upload(p, &L->w_mfma);
     }
     std::vector<float> f((size_t)taps * cin * cout);
@@ -2270,6 +2634,7 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
 void free_layer(ConvW* L) {
     if (L->w_mfma) (void)hipFree(L->w_mfma);
     if (L->w_lo) (void)hipFree(L->w_lo);
+    if (L->w8) (void)hipFree(L->w8);
     if (L->w_f32) (void)hipFree(L->w_f32);
     if (L->bias) (void)hipFree(L->bias);
     *L = ConvW();
@@ -2297,6 +2662,8 @@ struct NetWeights {  // everything tz_net_load_weights replaces, so a failed loa
     std::vector<ConvW> res;
     uint16_t* tower_w = nullptr;
     uint16_t* tower_w_lo = nullptr;
+    unsigned char* tower_w8 = nullptr;
+    float* c8_scales = nullptr;
     float* tower_bias = nullptr;
     float* heads = nullptr;
     ConvW rnd[2][3];
@@ -2313,9 +2680,13 @@ void free_weights(NetWeights& w) {
     w.res.clear();
     if (w.tower_w) (void)hipFree(w.tower_w);
     if (w.tower_w_lo) (void)hipFree(w.tower_w_lo);
+    if (w.tower_w8) (void)hipFree(w.tower_w8);
+    if (w.c8_scales) (void)hipFree(w.c8_scales);
     if (w.tower_bias) (void)hipFree(w.tower_bias);
     w.tower_w = nullptr;
     w.tower_w_lo = nullptr;
+    w.tower_w8 = nullptr;
+    w.c8_scales = nullptr;
     w.tower_bias = nullptr;
     if (w.heads) (void)hipFree(w.heads);
     w.heads = nullptr;
@@ -2337,30 +2708,40 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
     int rc;
     if ((rc = get_tensor(m, "core.input_conv2d.weight", (size_t)FILTERS * cin * 9, w))) return rc;
     if ((rc = bn_fold(m, "core.batch_norm", FILTERS, scale, bias))) return rc;
-    const bool split = prec == TZ_PREC_F16X2;
-    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in, split))) return rc;
+    const bool split = prec == TZ_PREC_F16X2, c8 = prec == TZ_PREC_F16C8;
+    // the first conv of TZ_PREC_F16C8 is the split form too: its input planes are built in the kernel, its k-loop is 9 steps
+    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in, split || c8))) return rc;
     W.res.resize(2 * net->blocks);
     for (int b = 0; b < net->blocks; b++)
         for (int h = 0; h < 2; h++) {
             const std::string p = "core.res_block_" + std::to_string(b) + (h ? ".b" : ".a");
             if ((rc = get_tensor(m, p + ".conv2d.weight", (size_t)FILTERS * FILTERS * 9, w))) return rc;
             if ((rc = bn_fold(m, p + ".batch_norm", FILTERS, scale, bias))) return rc;
-            if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h], split))) return rc;
+            if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h], split, c8))) return rc;
         }
     if (prec != TZ_PREC_F32 && net->blocks > 0) {  // the fused tower kernel reads all layers from one buffer
         const size_t layer_elems = (size_t)9 * 8 * 16 * 64 * 8, nl = W.res.size();
         TZ_HIP(hipMalloc(&W.tower_w, nl * layer_elems * 2));
         if (split) TZ_HIP(hipMalloc(&W.tower_w_lo, nl * layer_elems * 2));
+        const size_t layer_bytes8 = (size_t)9 * 2 * 16 * 2 * 64 * 32;
+        if (c8) TZ_HIP(hipMalloc(&W.tower_w8, nl * layer_bytes8));
         TZ_HIP(hipMalloc(&W.tower_bias, nl * FILTERS * sizeof(float)));
         for (size_t l = 0; l < nl; l++) {
             TZ_HIP(hipMemcpy(W.tower_w + l * layer_elems, W.res[l].w_mfma, layer_elems * 2, hipMemcpyDeviceToDevice));
             if (split) TZ_HIP(hipMemcpy(W.tower_w_lo + l * layer_elems, W.res[l].w_lo, layer_elems * 2, hipMemcpyDeviceToDevice));
+            if (c8) TZ_HIP(hipMemcpy(W.tower_w8 + l * layer_bytes8, W.res[l].w8, layer_bytes8, hipMemcpyDeviceToDevice));
             TZ_HIP(hipMemcpy(W.tower_bias + l * FILTERS, W.res[l].bias, FILTERS * sizeof(float), hipMemcpyDeviceToDevice));
         }
     }
     if ((rc = get_tensor(m, "policy.conv2d.weight", (size_t)net->pol_ch * FILTERS * 9, w))) return rc;
     if ((rc = get_tensor(m, "policy.conv2d.bias", net->pol_ch, bias))) return rc;
-    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy, split))) return rc;
+    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy, split, c8))) return rc;
+    if (c8) {
+        std::vector<float> cs;
+        for (auto& l : W.res) cs.push_back(l.c8_scale);
+        cs.push_back(W.policy.c8_scale);
+        if ((rc = upload(cs, &W.c8_scales))) return rc;
+    }
     // heads
     std::vector<float> hv, hu, lv, lu, t1;
     if ((rc = get_tensor(m, "value.conv2d.weight", FILTERS, hv))) return rc;
@@ -2623,8 +3004,8 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
 template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
-    constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * sizeof(int);
-    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
+    constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * (SP == 2 ? sizeof(uint16_t) : sizeof(int));
+    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP == 2 ? 20 : SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
     static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
     auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
@@ -2744,6 +3125,9 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.w_in_lo = net->conv_in.w_lo;
     a.w_lo = net->tower_w_lo;
     a.w_pol_lo = net->policy.w_lo;
+    a.w8 = net->tower_w8;
+    a.w_pol8 = net->policy.w8;
+    a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
 #ifdef TZ_ABLATIONS
     if (getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 8) {
@@ -2760,6 +3144,15 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
             case 4: return launch_net<4, 1, _Float16, false, 6, 1>(a, max_positions, st);
             case 5: return launch_net<5, 1, _Float16, true, 4, 1>(a, max_positions, st);
             case 6: return launch_net<6, 2, _Float16, false, 2, 1>(a, max_positions, st);
+        }
+        return tz_fail(TZ_EINVAL, "net: unsupported board size");
+    }
+    if (net->precision == TZ_PREC_F16C8) {   // same workgroups as the split form (20 planes instead of 16: the tap table halves)
+        switch (net->n) {
+            case 3: return launch_net<3, 1, _Float16, false, 8, 2>(a, max_positions, st);
+            case 4: return launch_net<4, 1, _Float16, false, 6, 2>(a, max_positions, st);
+            case 5: return launch_net<5, 1, _Float16, true, 4, 2>(a, max_positions, st);
+            case 6: return launch_net<6, 2, _Float16, false, 2, 2>(a, max_positions, st);
         }
         return tz_fail(TZ_EINVAL, "net: unsupported board size");
     }
@@ -2868,8 +3261,9 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     const bool need_planes = !bf;   // the MFMA path builds its planes in LDS; SimHash reads the packed states (simhash_state_kernel)
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
-    const bool split = net->precision == TZ_PREC_F16X2;
-    if (split && !(net->blocks > 0 && net->tower_w_lo)) return tz_fail(TZ_EINVAL, "forward: TZ_PREC_F16X2 needs a network with at least one residual block");
+    const bool split = prec_is_split(net->precision);
+    if (split && !(net->blocks > 0 && (net->tower_w_lo || net->tower_w8)))
+        return tz_fail(TZ_EINVAL, "forward: TZ_PREC_F16X2 / TZ_PREC_F16C8 need a network with at least one residual block");
     if (bf && net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split)) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (net->profile) {
@@ -3031,7 +3425,7 @@ int tz_net_create(int board_n, int arch, int device_id, int precision, int block
     else if (arch != TZ_ARCH_TEST) return tz_fail(TZ_EINVAL, "tz_net_create: unknown architecture");
     if (board_n && board_n != n) return tz_fail(TZ_EINVAL, "tz_net_create: board size does not match the architecture");
     if (n < 3 || n > 6) return tz_fail(TZ_EINVAL, "tz_net_create: board size must be 3..6");
-    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16 && precision != TZ_PREC_F16X2)
+    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16 && precision != TZ_PREC_F16X2 && precision != TZ_PREC_F16C8)
         return tz_fail(TZ_EINVAL, "tz_net_create: bad precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -3084,6 +3478,8 @@ static int net_apply_store(tz_net* net, TensorStore&& store) {
     old.res = net->res;
     old.tower_w = net->tower_w;
     old.tower_w_lo = net->tower_w_lo;
+    old.tower_w8 = net->tower_w8;
+    old.c8_scales = net->c8_scales;
     old.tower_bias = net->tower_bias;
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)
@@ -3100,6 +3496,8 @@ static int net_apply_store(tz_net* net, TensorStore&& store) {
     net->res = W.res;
     net->tower_w = W.tower_w;
     net->tower_w_lo = W.tower_w_lo;
+    net->tower_w8 = W.tower_w8;
+    net->c8_scales = W.c8_scales;
     net->tower_bias = W.tower_bias;
     net->heads = W.heads;
     for (int a = 0; a < 2; a++)
@@ -3565,6 +3963,8 @@ int tz_net_destroy(tz_net* net) {
     old.res = net->res;
     old.tower_w = net->tower_w;
     old.tower_w_lo = net->tower_w_lo;
+    old.tower_w8 = net->tower_w8;
+    old.c8_scales = net->c8_scales;
     old.tower_bias = net->tower_bias;
     old.heads = net->heads;
     for (int a = 0; a < 2; a++)

@@ -56,7 +56,7 @@ def legal_mask(states, n, half_komi=4):
     return mask
 
 
-def errors_against_f32(arch, weights, states, precisions=("f16", "f16x2", "bf16"), n=0, blocks=0, device=0, legal=None):
+def errors_against_f32(arch, weights, states, precisions=("f16", "f16c8", "f16x2", "bf16"), n=0, blocks=0, device=0, legal=None):
     """{precision: {max_abs_logit_err, max_abs_value_err, max_abs_ube_err}} + the fp32 path's output scale.  With `legal` (a mask
     from legal_mask) also the same over the legal-move logits only: a trained net's illegal-move logits are masked out of its loss
     and drift far from the scale of the ones a search reads."""

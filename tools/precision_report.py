@@ -41,7 +41,7 @@ def main():
     out["random_init_scale"] = P.errors_against_f32(A.ARCH_NET5, w0, states)
     w1 = P.trained_scale_weights(A.ARCH_NET5, states, seed=123)
     out["trained_scale"] = P.errors_against_f32(A.ARCH_NET5, w1, states)
-    out["net_kernel_ms_per_%d_positions" % games] = {p: kernel_ms(p, w0, games, sims) for p in ("f16", "bf16", "f16x2")}
+    out["net_kernel_ms_per_%d_positions" % games] = {p: kernel_ms(p, w0, games, sims) for p in ("f16", "bf16", "f16c8", "f16x2")}
     print(json.dumps(out, indent=1))
 
 
