@@ -107,37 +107,40 @@ def cpu_baseline(seconds=12.0):
 
 
 def precision_report(A, SP, W, args, primary_sims_per_s, moves=2):
-    """Throughput of the precision the main measurement did not run (same workload, `moves` timed moves after one warm-up
-    move) and the measured output errors of both against the library's fp32 path at random-init and at trained logit scale
-    (takzero_amd/precision.py).  The north star's tolerance (logits within 1e-3 of the fp32 path) is met by f16x2 at any
-    scale and by f16 only while |logit| <~ 1."""
+    """Throughput of the precisions the main measurement did not run (same workload, `moves` timed moves after one warm-up
+    move each) and the measured output errors of all of them against the library's fp32 path at random-init and at trained
+    logit scale (takzero_amd/precision.py).  The north star's tolerance (logits within 1e-3 of the fp32 path) is met by f16c8
+    (fp16 products + FP8 correction products) and f16x2 (hi / lo fp16 operands) at any scale, by f16 only while |logit| <~ 1."""
     from takzero_amd import precision as P
 
-    other = "f16x2" if args.precision == "f16" else "f16"
-    net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_NAMES[other])
-    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
-    mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
-    sp = SP.NativeSelfPlay(mcts, args.sims, seed=0, shard=0, search=args.search, sampled_actions=64)
-    sp.play_move()
-    mcts.sync()
-    s0 = mcts.counters()[0]
-    t0 = time.perf_counter()
-    for _ in range(moves):
+    names = ("f16", "f16c8", "f16x2")
+    rates = {args.precision: primary_sims_per_s}
+    for other in names:
+        if other in rates:
+            continue
+        net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_NAMES[other])
+        net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
+        mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
+        sp = SP.NativeSelfPlay(mcts, args.sims, seed=0, shard=0, search=args.search, sampled_actions=64)
         sp.play_move()
-    mcts.sync()
-    dt = time.perf_counter() - t0
-    rate = (mcts.counters()[0] - s0) / dt
-    sp.close()
-    mcts.close()
-    net.close()
+        mcts.sync()
+        s0 = mcts.counters()[0]
+        t0 = time.perf_counter()
+        for _ in range(moves):
+            sp.play_move()
+        mcts.sync()
+        dt = time.perf_counter() - t0
+        rates[other] = (mcts.counters()[0] - s0) / dt
+        sp.close()
+        mcts.close()
+        net.close()
     states = P.sample_positions(N_BOARD, HALF_KOMI, 64, seed=7)
     w0 = W.init_weights(W.ARCH_NET5, seed=123)
-    e0 = P.errors_against_f32(A.ARCH_NET5, w0, states, precisions=("f16", "f16x2"))
-    e1 = P.errors_against_f32(A.ARCH_NET5, P.trained_scale_weights(A.ARCH_NET5, states, seed=123), states, precisions=("f16", "f16x2"))
-    rates = {args.precision: primary_sims_per_s, other: rate}
+    e0 = P.errors_against_f32(A.ARCH_NET5, w0, states, precisions=names)
+    e1 = P.errors_against_f32(A.ARCH_NET5, P.trained_scale_weights(A.ARCH_NET5, states, seed=123), states, precisions=names)
     out = {"reference": e0["reference"], "positions": e0["positions"], "tolerance": "north star: logits within 1e-3 (absolute) of the fp32 path",
-           "timed_moves_of_the_second_precision": moves}
-    for p in ("f16", "f16x2"):
+           "timed_moves_of_the_other_precisions": moves}
+    for p in names:
         out[p] = {"sims_per_s": rates[p],
                   "random_init_scale": dict(e0[p], logit_scale=e0["logit_scale"]),
                   "trained_scale": dict(e1[p], logit_scale=e1["logit_scale"]),
@@ -161,10 +164,11 @@ def main():
     ap.add_argument("--driver", choices=["native", "python"], default="native",
                     help="native = the self-play outer loop in csrc/tz_host.cpp (tz_selfplay_*); python = its mirror in "
                          "takzero_amd/selfplay.py")
-    ap.add_argument("--precision", choices=["bf16", "f16", "f16x2"], default=os.environ.get("TZ_PRECISION", "f16"),
-                    help="arithmetic of the MFMA path: f16 (default) = fp16 storage, fp32 accumulate, ~2e-4 relative logit error; "
-                         "f16x2 = split precision (hi/lo fp16 operands, 3 MFMAs per product), within 1e-3 absolute at trained logit "
-                         "scale, ~3x the MFMA work; bf16 = the f16 kernels 5 %% faster at 1e-3 .. 7e-3 (random-init scale)")
+    ap.add_argument("--precision", choices=["bf16", "f16", "f16c8", "f16x2"], default=os.environ.get("TZ_PRECISION", "f16"),
+                    help="arithmetic of the MFMA path: f16 (default) = fp16 storage, fp32 accumulate, ~1e-3 relative logit error "
+                         "through the 41 convs; f16c8 = the fp16 product plus FP8 (E4M3) correction products (1.4e-4 absolute at "
+                         "trained logit scale, ~2.3x the f16 kernel time); f16x2 = split precision (hi/lo fp16 operands, 3 MFMAs per "
+                         "product: 2.4e-5, ~3x); bf16 = the f16 kernels 5 %% faster at 1e-3 .. 7e-3 (random-init scale)")
     ap.add_argument("--no-precision-report", action="store_true",
                     help="skip the second measurement (N = 1 only): throughput of the other precision and the measured logit errors")
     args = ap.parse_args()
@@ -345,18 +349,26 @@ def main():
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
             traffic = None   # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/)
             tpath = os.path.join(ROOT, "profiles", "tower_pmc_traffic.json")
-            if FUSED_MODE == 2 and args.games == GAMES and os.path.exists(tpath):
+            split = args.precision in ("f16x2", "f16c8")
+            if FUSED_MODE == 2 and args.games == GAMES and os.path.exists(tpath) and not split:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            kernel_name, rows, issued = KERNEL_NAME, "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS, ISSUED_FLOP_PER_LAUNCH_POS
+            if split and FUSED_MODE == 2:
+                # 4 boards per workgroup (7 row tiles, 49 of 63 pairs issued) and three products per MAC: hi*hi on fp16 MFMAs, the two
+                # corrections on fp16 MFMAs (f16x2) or on FP8 MFMAs of 4x the K at twice the rate (f16c8) - the same issued FLOP count
+                kernel_name = ("net_mfma_kernel<5,4,1,SP=%d> (%s; same fusion)" %
+                               ((1, "hi/lo fp16 operands, 3 fp16 MFMAs per product") if args.precision == "f16x2"
+                                else (2, "fp16 product + 2 correction products on FP8 E4M3 copies, v_mfma_f32_16x16x128_f8f6f4")))
+                rows = "square-major, 49 of 63 (tap, row tile) pairs per tower conv issued"
+                issued = 3 * (2 * 16 * 256 * 32 * (9 * 7 * 1 + TOWER_LAYERS * 49 * 8 + 49 * 8 * 0.5)) / 4.0
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "traffic_source": ("stored figure, not measured in this run: profiles/tower_pmc_traffic.json (rocprofv3 --pmc "
                                                   "passes of the same command; 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction)"
                                                   if traffic is not None else None),
-                               "kernel": KERNEL_NAME,
-                               "rows": "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS
-                               if FUSED_MODE == 2 else "board-major",
-                               "issued_tflops": (ISSUED_FLOP_PER_LAUNCH_POS * per_launch_positions / (avg_ms * 1e-3) / 1e12
-                                                 if FUSED_MODE == 2 else None),
+                               "kernel": kernel_name,
+                               "rows": rows if FUSED_MODE == 2 else "board-major",
+                               "issued_tflops": (issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 if FUSED_MODE == 2 else None),
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
@@ -368,7 +380,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the checker must not take the measurement down with it
                 out["cpu_baseline"] = {"error": repr(e)}
-        if world == 1 and not args.no_precision_report and args.games == GAMES and args.precision in ("f16", "f16x2"):
+        if world == 1 and not args.no_precision_report and args.games == GAMES and args.precision in ("f16", "f16c8", "f16x2"):
             # the other precision's throughput and both measured errors: close the first engine (66 GB of pools)
             sp.close()
             mcts.close()

@@ -51,7 +51,7 @@ def test_hip_forward_matches_the_golden_vectors(case):
     n = case["n"]
     states = np.array([A.state_from_tps(p["tps"], n, case["half_komi"]) for p in case["positions"]], dtype=A.STATE_DTYPE)
     acts = [p["legal"] for p in case["positions"]]
-    for prec, tol in ((A.PREC_F32, 1e-4), (A.PREC_F16X2, 1e-4), (A.PREC_F16, 1e-3), (A.PREC_BF16, 2e-2)):
+    for prec, tol in ((A.PREC_F32, 1e-4), (A.PREC_F16X2, 1e-4), (A.PREC_F16C8, 2e-4), (A.PREC_F16, 1e-3), (A.PREC_BF16, 2e-2)):
         net = A.Net(arch=case["arch"], n=n, precision=prec, blocks=case["blocks"]).load_tensors(w)
         logits, value, _var = net.policy_value_uncertainty(states, acts)
         _pol, _val, ube = net.forward_raw(states)
