@@ -425,6 +425,9 @@ int tz_debug_tower_bench(tz_net* net, int variant, int positions, int iters, flo
 /* Diagnostic (builds with --ablations, TZ_NET_ABL=8): in-kernel shader clock of the last stamped launch of the net kernel
  * (median over workgroups of delta s_memtime / delta s_memrealtime x 100 MHz) and the median duration of its tower part. */
 int tz_debug_net_clock(tz_net* net, double* mhz_out, double* tower_us_out);
+/* diagnostic builds: the raw in-kernel stamps of the last stamped launch, [workgroup][4] (TZ_NET_ABL=8: memtime, memrealtime before
+   and after the tower; TZ_NET_ABL=16: memtime after the barrier, the k-loop, the barrier and the epilogue of the middle layer) */
+int tz_debug_net_stamps(tz_net* net, unsigned long long* out, int max_groups, int* groups_out);
 
 #ifdef __cplusplus
 }

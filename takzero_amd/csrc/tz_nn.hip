@@ -1967,6 +1967,9 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 for (int rt = 0; rt < RT; rt++) accc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
+        if constexpr (ABL & 16) {   // phase stamps of the middle layer: [0] barrier passed, [1] k-loop done, [2] barrier passed, [3] epilogue done
+            if (layer == a.nlayers / 2 && lane == 0 && wave == 0 && a.dbg) a.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        }
         if constexpr (SP == 2) {
             auto wl = [&](int tap, int kc, int j) -> ex8 {
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
@@ -1994,7 +1997,13 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             else if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 7)>(lds, tap_table, lane, acc, wl);
             else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
         }
+        if constexpr (ABL & 16) {
+            if (layer == a.nlayers / 2 && lane == 0 && wave == 0 && a.dbg) a.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        }
         __syncthreads();
+        if constexpr (ABL & 16) {
+            if (layer == a.nlayers / 2 && lane == 0 && wave == 0 && a.dbg) a.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+        }
         const bool to_second = (layer & 1) == 0;
 #pragma unroll
         for (int j = 0; j < RN; j++) {
@@ -2048,6 +2057,9 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                     *slot = pk;
                 }
             }
+        }
+        if constexpr (ABL & 16) {
+            if (layer == a.nlayers / 2 && lane == 0 && wave == 0 && a.dbg) a.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
         }
     }
     __syncthreads();  // the image now holds the tower's output
@@ -3067,6 +3079,7 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
                 case 3: return launch_net<5, 1, ET, true, 8, 0, 3>(a, max_positions, st);
                 case 4: return launch_net<5, 1, ET, true, 8, 0, 4>(a, max_positions, st);
                 case 8: return launch_net<5, 1, ET, true, 8, 0, 8>(a, max_positions, st);
+                case 16: return launch_net<5, 1, ET, true, 8, 0, 16>(a, max_positions, st);
                 default: break;
             }
         }
@@ -3130,10 +3143,10 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
 #ifdef TZ_ABLATIONS
-    if (getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 8) {
+    if (getenv("TZ_NET_ABL") && (atoi(getenv("TZ_NET_ABL")) == 8 || atoi(getenv("TZ_NET_ABL")) == 16)) {
         if (!net->dbg_buf) TZ_HIP(hipMalloc(&net->dbg_buf, (size_t)65536 * 4 * sizeof(unsigned long long)));
         a.dbg = reinterpret_cast<unsigned long long*>(net->dbg_buf);
-        net->dbg_groups = (max_positions + 7) / 8;
+        net->dbg_groups = (max_positions + (prec_is_split(net->precision) ? 3 : 7)) / (prec_is_split(net->precision) ? 4 : 8);
     }
 #endif
     if (net->precision == TZ_PREC_F16X2) {
@@ -3148,6 +3161,9 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
         return tz_fail(TZ_EINVAL, "net: unsupported board size");
     }
     if (net->precision == TZ_PREC_F16C8) {   // same workgroups as the split form (20 planes instead of 16: the tap table halves)
+#ifdef TZ_ABLATIONS
+        if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 16) return launch_net<5, 1, _Float16, true, 4, 2, 16>(a, max_positions, st);
+#endif
         switch (net->n) {
             case 3: return launch_net<3, 1, _Float16, false, 8, 2>(a, max_positions, st);
             case 4: return launch_net<4, 1, _Float16, false, 6, 2>(a, max_positions, st);
@@ -3950,6 +3966,17 @@ int tz_debug_net_clock(tz_net* net, double* mhz_out, double* tower_us_out) {
     std::sort(us.begin(), us.end());
     if (mhz_out) *mhz_out = mhz[mhz.size() / 2];
     if (tower_us_out) *tower_us_out = us[us.size() / 2];
+    return TZ_OK;
+}
+
+// diagnostic builds: the raw stamps of the last stamped launch, [workgroup][4]
+int tz_debug_net_stamps(tz_net* net, unsigned long long* out, int max_groups, int* groups_out) {
+    if (!net || !net->dbg_buf || net->dbg_groups <= 0) return tz_fail(TZ_ESTATE, "tz_debug_net_stamps: no stamped launch (build --ablations, TZ_NET_ABL=8 or 16)");
+    TZ_HIP(hipSetDevice(net->device));
+    TZ_HIP(hipDeviceSynchronize());
+    const int g = std::min(max_groups, net->dbg_groups);
+    TZ_HIP(hipMemcpy(out, net->dbg_buf, (size_t)g * 4 * 8, hipMemcpyDeviceToHost));
+    if (groups_out) *groups_out = g;
     return TZ_OK;
 }
 
