@@ -62,7 +62,7 @@ def main():
     sp2.close()
     fresh.close()
     net.close()
-    report = P.errors_against_f32(A.ARCH_NET5, weights, states, precisions=("f16", "f16x2", "bf16"), legal=P.legal_mask(states, 5))
+    report = P.errors_against_f32(A.ARCH_NET5, weights, states, precisions=("f16", "f16c8", "f16x2", "bf16"), legal=P.legal_mask(states, 5))
     out = {"net": "net5 trained by the repo's own closed loop (self-play Gumbel 64 / k 16 on 4096 games -> learn, batch 128)",
            "training_steps": done, "targets_generated": targets, "loss_history": history[::max(1, len(history) // 10)],
            "seconds": round(time.time() - t0, 1), "errors_vs_fp32_path": report}
