@@ -346,7 +346,7 @@ def test_native_drivers_write_the_same_bytes_over_the_gpu_engine_and_over_the_or
     assert ("\n".join(lines) + "\n").encode() == want["consumers"]
 
 
-@pytest.mark.parametrize("kind,sims,k,prec", [(0, 24, 64, 2), (1, 16, 4, 0), (1, 16, 4, 3)])   # fp16, bf16, split precision
+@pytest.mark.parametrize("kind,sims,k,prec", [(0, 24, 64, 2), (1, 16, 4, 0), (1, 16, 4, 3), (0, 24, 64, 4)])   # fp16, bf16, split precision, fp16 + FP8 corrections
 def test_whole_loop_bytes_with_the_real_network(tmp_path, kind, sims, k, prec):
     """The same byte-for-byte statement with the network in the loop: the HIP engine (fused trunk kernel, leaf batches
     compacted on the device) against the oracle search whose Agent is that HIP network called through tz_net_eval."""
