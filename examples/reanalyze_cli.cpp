@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
         else if (a == "--world") world = atoi(next());
         else if (a == "--device") device = atoi(next());
         else if (a == "--f16x2") precision = TZ_PREC_F16X2;
+        else if (a == "--f16c8") precision = TZ_PREC_F16C8;
         else if (a == "--bf16") precision = TZ_PREC_BF16;
         else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -86,7 +87,7 @@ int main(int argc, char** argv) {
     if (directory.empty()) {
         fprintf(stderr, "usage: reanalyze_cli --directory DIR [--model FILE --watch model_latest.ot --arch 4|5|6|100 --n N --blocks K --games B "
                         "--sims S --search puct|gumbel --sampled-actions K --iterations I --min-positions P --wait-limit SECONDS --seed X "
-                        "--rank R --world N --device G --bf16|--f16x2]\n");
+                        "--rank R --world N --device G --bf16|--f16c8|--f16x2]\n");
         return 2;
     }
     if (arch == TZ_ARCH_NET5) n = 5;

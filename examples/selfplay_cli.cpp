@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
         else if (a == "--comm") comm_kind = next();
         else if (a == "--comm-dir") comm_dir = next();
         else if (a == "--f16x2") precision = TZ_PREC_F16X2;
+        else if (a == "--f16c8") precision = TZ_PREC_F16C8;
         else if (a == "--f16") precision = TZ_PREC_F16;
         else if (a == "--bf16") precision = TZ_PREC_BF16;
         else if (a == "--exploration") exploration = 1;
