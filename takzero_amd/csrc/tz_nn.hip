@@ -3164,6 +3164,9 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
 #ifdef TZ_ABLATIONS
         if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 16) return launch_net<5, 1, _Float16, true, 4, 2, 16>(a, max_positions, st);
 #endif
+        // small batches (the Agent surface at the reference's batch of 128): one or two boards per workgroup, as in the fp16 form
+        if (net->n == 5 && net_small_p(max_positions) == 1) return launch_net<5, 1, _Float16, false, 1, 2>(a, max_positions, st);
+        if (net->n == 5 && net_small_p(max_positions) == 2) return launch_net<5, 1, _Float16, false, 2, 2>(a, max_positions, st);
         switch (net->n) {
             case 3: return launch_net<3, 1, _Float16, false, 8, 2>(a, max_positions, st);
             case 4: return launch_net<4, 1, _Float16, false, 6, 2>(a, max_positions, st);

@@ -208,6 +208,26 @@ def test_forward_is_batch_composition_independent(oracle, prec, n):
         assert np.array_equal(pol[perm], pol2) and np.array_equal(val[perm], val2) and np.array_equal(ube[perm], ube2), count
 
 
+@pytest.mark.parametrize("prec", [2, 4])
+def test_workgroup_forms_give_the_same_bits(oracle, prec):
+    """Small batches run on 1- and 2-board workgroups (board-major rows), large ones on 8 (fp16) or 4 (fp16 + FP8 corrections)
+    boards in square-major order with the all-padding (tap, tile) pairs left out: a position's outputs are the same bits in
+    every form (same k order, what is skipped adds exact zeros)."""
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    net = A.Net(arch=A.ARCH_NET5, precision=prec)
+    net.load_tensors(W.init_weights(W.ARCH_NET5, seed=9))
+    base = O.states_array(random_positions(oracle, O, 5, 4, 64, 21))
+    states = np.concatenate([base] * 18)[:1100]
+    big = net.forward_raw(states)                      # > 1024 positions: the full-size workgroups
+    for count in (1030, 600, 300, 100):                # full size again (ragged), 4, 2 and 1 boards per workgroup
+        part = net.forward_raw(states[:count])
+        for x, y in zip(big, part):
+            assert np.array_equal(x[:count], y), (prec, count)
+    net.close()
+
+
 def test_failed_load_keeps_old_weights(oracle, tmp_path):
     A = require_gpu()
     from takzero_amd import weights as W
