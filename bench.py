@@ -369,6 +369,10 @@ def main():
                                "kernel": kernel_name,
                                "rows": rows if FUSED_MODE == 2 else "board-major",
                                "issued_tflops": (issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 if FUSED_MODE == 2 else None),
+                               # the MFMA mix's own ceiling: fp16 MFMAs at 2.5 PFLOP/s; f16c8 issues a third of its FLOPs there and two
+                               # thirds on FP8 MFMAs at 5 PFLOP/s -> 3.75 PFLOP/s for the mix
+                               "issued_frac_of_mfma_mix_peak": (issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 /
+                                                                (3750.0 if args.precision == "f16c8" else PEAK_BF16_TFLOPS) if FUSED_MODE == 2 else None),
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
