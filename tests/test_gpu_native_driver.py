@@ -293,6 +293,65 @@ def test_two_shards_of_the_cpp_program_hand_over_to_rank_0(oracle, tmp_path):
     _check_lines(oracle, n, targets, replays, "gumbel")
 
 
+def test_two_shards_through_the_rccl_side_of_the_communicator(oracle, tmp_path):
+    """The RCCL side of csrc/tz_comm.cpp with two ranks on this box's one GPU.  RCCL itself refuses two ranks on one device, so
+    the library is pointed (TZ_RCCL_LIB) at a stand-in with RCCL's entry points and semantics on device buffers
+    (tests/mock_rccl.cpp: bytes move through files): everything above it is the code an N-GPU job runs - the unique-id rendezvous,
+    ncclCommInitRank, the staging buffers on the device, the stream order, all-gather of counts then of padded records at world 2,
+    the broadcast of a reloaded model from rank 0 - and the result must be what the fs transport gives: rank 0 holds everybody's
+    lines, the two shards play different games, rank 1 writes nothing, and the model rank 0 picked up reached rank 1."""
+    import subprocess
+
+    require_gpu()
+    from takzero_amd import formats as F
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    mock = str(tmp_path / "libmockrccl.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-w", os.path.join(root, "tests", "mock_rccl.cpp"), "-o", mock],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the stand-in library here: " + r.stderr[-300:])
+    exe = _build_example(tmp_path, "selfplay_cli")
+    d, n = str(tmp_path / "run"), 4
+    os.makedirs(d)
+    os.makedirs(tmp_path / "xch")
+    open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    # a model for rank 0 to find at its first look: it has to reach rank 1 through the broadcast
+    ot.save_ot(os.path.join(d, "model_latest.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
+    env = dict(os.environ, TZ_RCCL_LIB=mock)
+    procs = [subprocess.Popen([exe, "--directory", d, "--arch", "100", "--n", str(n), "--blocks", "1", "--games", "32", "--sims", "16",
+                               "--sampled-actions", "4", "--search", "gumbel", "--moves", "70", "--wait-limit", "30", "--seed", "3",
+                               "--rank", str(rk), "--world", "2", "--comm", "rccl", "--comm-dir", str(tmp_path / "xch"), "--device", "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for rk in (0, 1)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1200:] for o in outs]
+    f0, f1 = _fields(outs[0][0]), _fields(outs[1][0])
+    assert f0["model_reloads"] == "1"                    # rank 0 loaded the archive; rank 1 got the variables over the communicator
+    targets = open(os.path.join(d, "targets-selfplay.txt"), "rb").read()
+    replays = open(os.path.join(d, "replays.txt"), "rb").read()
+    assert int(f0["targets"]) > 0 and int(f1["targets"]) > 0 and f0["targets"] != f1["targets"]
+    assert targets.count(b"\n") == int(f0["targets"]) + int(f1["targets"])
+    assert replays.count(b"\n") == int(f0["replays"]) + int(f1["replays"])
+    assert sorted(os.listdir(d)) == ["buffer_lengths.txt", "model_latest.ot", "replays.txt", "targets-selfplay.txt"]
+    _check_lines(oracle, n, targets, replays, "gumbel")
+    # the same job over the fs transport writes the same bytes (same seeds, same model): the transports are interchangeable
+    d2 = str(tmp_path / "run_fs")
+    os.makedirs(d2)
+    os.makedirs(tmp_path / "xch_fs")
+    open(os.path.join(d2, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
+    ot.save_ot(os.path.join(d2, "model_latest.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
+    procs = [subprocess.Popen([exe, "--directory", d2, "--arch", "100", "--n", str(n), "--blocks", "1", "--games", "32", "--sims", "16",
+                               "--sampled-actions", "4", "--search", "gumbel", "--moves", "70", "--wait-limit", "30", "--seed", "3",
+                               "--rank", str(rk), "--world", "2", "--comm", "fs", "--comm-dir", str(tmp_path / "xch_fs"), "--device", "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in (0, 1)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1200:] for o in outs]
+    assert open(os.path.join(d2, "targets-selfplay.txt"), "rb").read() == targets
+    assert open(os.path.join(d2, "replays.txt"), "rb").read() == replays
+
+
 @pytest.mark.parametrize("kind,sims,k,exploration,agent,n", [(0, 24, 64, 1, 2, 4), (1, 16, 4, 0, 2, 4), (1, 48, 8, 1, 1, 5), (2, 0, 64, 0, 1, 4)])
 def test_native_drivers_write_the_same_bytes_over_the_gpu_engine_and_over_the_oracle(tmp_path, kind, sims, k, exploration, agent, n):
     """The strongest statement about the whole loop: csrc/tz_host.cpp driving the HIP engine and the very same driver
