@@ -231,7 +231,7 @@ def main():
         from takzero_amd import comm as CM
 
         try:
-            if backend == "nccl":
+            if backend == "nccl" or os.environ.get("TZ_BENCH_COMM") == "rccl":   # TZ_BENCH_COMM=rccl: the RCCL communicator in a gloo rehearsal
                 ident = torch.zeros(CM.ID_BYTES, dtype=torch.uint8, device=dev)
                 if rank == 0:
                     ident = torch.frombuffer(bytearray(CM.unique_id()), dtype=torch.uint8).to(dev)

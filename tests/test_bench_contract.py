@@ -59,6 +59,32 @@ def test_two_rank_launch_as_the_driver_does_it():
 
 
 @pytest.mark.gpu
+def test_two_rank_launch_through_the_rccl_communicator_of_the_library(tmp_path):
+    """The same two-rank launch with the hand-over through the library's RCCL communicator - what the 8-GPU run does - on this
+    box's one GPU: RCCL refuses two ranks on one device, so TZ_RCCL_LIB points the library at the stand-in of tests/mock_rccl.cpp
+    (RCCL's entry points, bytes through files) and TZ_BENCH_COMM=rccl selects the communicator although the process group is
+    gloo.  Covers takzero_amd/comm.py's unique id, its broadcast to the ranks, tz_comm_create_rccl at world 2 and the per-move
+    all-gathers from Python."""
+    mock = str(tmp_path / "libmockrccl.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-w", os.path.join(ROOT, "tests", "mock_rccl.cpp"), "-o", mock],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the stand-in library here: " + r.stderr[-300:])
+    env = dict(os.environ, TZ_BENCH_BACKEND="gloo", TZ_BENCH_DEVICE="0", TZ_BENCH_COMM="rccl", TZ_RCCL_LIB=mock)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--games", "128", "--sims", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-800:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world"] == 2 and out["value"] > 0
+    assert out["exchange"]["transport"] == "rccl" and out["exchange"]["world"] == 2 and out["exchange"]["collectives"] == 1 + 3 * 3
+    assert "native_exchange_error" not in out["exchange"]
+
+
+@pytest.mark.gpu
 def test_the_rccl_set_up_of_a_multi_gpu_run_with_one_rank():
     """What the driver's N > 1 launch does before the timed region, on this box's one GPU (TZ_BENCH_FORCE_DIST=1): torchrun,
     process group over nccl (= RCCL), the all_reduce probe, the communicator id broadcast through it, the library's own RCCL
