@@ -1148,9 +1148,12 @@ struct IntC {
 // k_loop_256 with the tap loop unrolled and the all-zero (tap, row tile) pairs of the row map left out
 // ABL (diagnostic builds only, TZ_ABLATIONS): 1 = the activation fragments are read once and reused (no ds_read stream),
 // 2 = the weight fragments are fetched once and reused (no L2 stream), 4 = operands stream but no MFMA is issued.
+// ABL bit 32 (diagnostic builds): fairness between the two waves of a SIMD - every k-step a wave posts its step number in LDS, reads
+// its partner's (wave ^ 4) and lowers its own priority while it is ahead (fair_slots: 8 ints; fair_step0: the conv's first step)
 template <int NB, int P, int RNX, int PLANE, typename ET, int ABL = 0, typename WL>
 __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const int* tap_table, int lane,
-                                                f32x4 (&acc)[RowMap<NB, P, true>::RT][RNX], WL wl) {
+                                                f32x4 (&acc)[RowMap<NB, P, true>::RT][RNX], WL wl, int* fair_slots = nullptr, int fair_wave = 0,
+                                                int fair_step0 = 0) {
     typedef typename Elem<ET>::x8 ex8;
     typedef RowMap<NB, P, true> RM;
     constexpr int TAPS = 9, RT = RM::RT;
@@ -1177,6 +1180,16 @@ __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const 
         constexpr unsigned NEXT = tap + 1 < TAPS ? RM::tap_tile_mask(tap + 1 < TAPS ? tap + 1 : tap) : 0u;
 #pragma unroll
         for (int kc = 0; kc < 8; kc++) {
+            if constexpr ((ABL & 96) != 0) {
+                // bit 32: the decision is taken once per tap and held for its eight k-steps; bit 64: once per three taps
+                if (kc == 0 && ((ABL & 32) || tap % 3 == 0)) {
+                    const int step = fair_step0 + tap * 8 + kc;
+                    fair_slots[fair_wave] = step;
+                    const int other = __builtin_amdgcn_readfirstlane(fair_slots[fair_wave ^ 4]);
+                    if (other < step) __builtin_amdgcn_s_setprio(0);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
+            }
             if constexpr (!(ABL & 2)) {
                 if (kc + 2 < 8) {
 #pragma unroll
@@ -1222,7 +1235,7 @@ __device__ __forceinline__ void k_loop_256_skip(const unsigned char* lds, const 
                 }
             }
             // the issue order of k_loop_256: the MFMAs of a row tile, then the ds_read that refills its fragment
-            if constexpr (ABL == 0) {
+            if constexpr ((ABL & 7) == 0) {
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
                     if ((NOW >> rt) & 1) __builtin_amdgcn_sched_group_barrier(0x008, RNX, 0);
@@ -1994,7 +2007,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, frag * 1024, 0));
             };
             if constexpr (TT) k_loop_256_ring<NB, P, RN, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, acc, wl);
-            else if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 7)>(lds, tap_table, lane, acc, wl);
+            else if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 103)>(lds, tap_table, lane, acc, wl, reinterpret_cast<int*>(hscratch), wave, layer * 72);
             else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
         }
         if constexpr (ABL & 16) {
@@ -3080,6 +3093,10 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
                 case 4: return launch_net<5, 1, ET, true, 8, 0, 4>(a, max_positions, st);
                 case 8: return launch_net<5, 1, ET, true, 8, 0, 8>(a, max_positions, st);
                 case 16: return launch_net<5, 1, ET, true, 8, 0, 16>(a, max_positions, st);
+                case 32: return launch_net<5, 1, ET, true, 8, 0, 32>(a, max_positions, st);
+                case 48: return launch_net<5, 1, ET, true, 8, 0, 48>(a, max_positions, st);
+                case 64: return launch_net<5, 1, ET, true, 8, 0, 64>(a, max_positions, st);
+                case 80: return launch_net<5, 1, ET, true, 8, 0, 80>(a, max_positions, st);
                 default: break;
             }
         }
@@ -3143,7 +3160,7 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
 #ifdef TZ_ABLATIONS
-    if (getenv("TZ_NET_ABL") && (atoi(getenv("TZ_NET_ABL")) == 8 || atoi(getenv("TZ_NET_ABL")) == 16)) {
+    if (getenv("TZ_NET_ABL") && (atoi(getenv("TZ_NET_ABL")) == 8 || (atoi(getenv("TZ_NET_ABL")) & 16))) {
         if (!net->dbg_buf) TZ_HIP(hipMalloc(&net->dbg_buf, (size_t)65536 * 4 * sizeof(unsigned long long)));
         a.dbg = reinterpret_cast<unsigned long long*>(net->dbg_buf);
         net->dbg_groups = (max_positions + (prec_is_split(net->precision) ? 3 : 7)) / (prec_is_split(net->precision) ? 4 : 8);

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["TZ_NET_ABL"] = "16"
+os.environ["TZ_NET_ABL"] = os.environ.get("TZ_NET_ABL", "16")
 import takzero_amd.api as A  # noqa: E402
 from takzero_amd import weights as W  # noqa: E402
 
