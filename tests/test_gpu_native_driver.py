@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from gpu_util import require_gpu
+from gpu_util import random_positions, require_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -261,6 +261,51 @@ def test_closed_loop_of_the_three_cpp_programs_over_ot_files(oracle, tmp_path):
     re_targets = open(os.path.join(d, "targets-reanalyze.txt"), "rb").read()
     assert re_targets.count(b"\n") == 12 * 64
     _check_lines(oracle, n, re_targets, None, "gumbel", game_values=False)
+
+
+def test_evaluation_cpp_program_matches_models_up(oracle, tmp_path):
+    """examples/evaluation_cli.cpp = the reference's `evaluation` binary (evaluation/src/main.rs:131-222) over the C ABI: picks
+    two of the directory's model_<steps>.ot files (never model_latest.ot), loads them with load_partial semantics, starts the
+    games from an opening book or from openings with two or three random moves, and plays tz_compete both ways round (tz_compete
+    itself is checked against the oracle in test_puzzle.py / test_gpu_drivers.py)."""
+    import re
+    import subprocess
+
+    require_gpu()
+    from takzero_amd import ot
+    from takzero_amd import weights as W
+
+    exe = _build_example(tmp_path, "evaluation_cli")
+    d, n = str(tmp_path / "models"), 4
+    os.makedirs(d)
+    for steps, seed in ((0, 1), (100, 2), (200, 3)):
+        ot.save_ot(os.path.join(d, "model_%07d.ot" % steps), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=seed))
+    ot.save_ot(os.path.join(d, "model_latest.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=3))
+    common = [exe, "--model-path", d, "--arch", "100", "--n", str(n), "--blocks", "1", "--games", "16", "--sampled-actions", "4",
+              "--budget", "16", "--max-moves", "80", "--rounds", "3", "--seed", "5"]
+    book = tmp_path / "book.tps"
+    states = random_positions(oracle, O, n, 4, 24, 11, max_ply=6)
+    book.write_text("".join(O.to_tps(oracle, s) + "\n" for s in states))
+    for extra in ([], ["--opening-book", str(book)]):
+        r = subprocess.run(common + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
+        lines = [ln for ln in r.stdout.splitlines() if " vs. " in ln]
+        assert len(lines) == 6, r.stdout                      # three match-ups, each played both ways round
+        for i in range(0, 6, 2):
+            m1 = re.fullmatch(r"(\S+) vs\. (\S+): Evaluation \{ wins: (\d+), losses: (\d+), draws: (\d+) \} ([0-9.]+)%", lines[i])
+            m2 = re.fullmatch(r"(\S+) vs\. (\S+): Evaluation \{ wins: (\d+), losses: (\d+), draws: (\d+) \} ([0-9.]+)%", lines[i + 1])
+            assert m1 and m2, lines[i:i + 2]
+            assert m1.group(1) == m2.group(2) and m1.group(2) == m2.group(1) and m1.group(1) != m1.group(2)
+            for m in (m1, m2):
+                assert m.group(1) in ("model_0000000.ot", "model_0000100.ot", "model_0000200.ot") and "latest" not in m.group(2)
+                w, l, dr = int(m.group(3)), int(m.group(4)), int(m.group(5))
+                assert 0 < w + l + dr <= 16
+                assert abs(float(m.group(6)) - 100.0 * w / (w + l + dr)) < 0.06
+    # too few models: the reference sleeps and looks again; a bounded run with --sleep 0 says so and stops
+    os.remove(os.path.join(d, "model_0000100.ot"))
+    os.remove(os.path.join(d, "model_0000200.ot"))
+    r = subprocess.run(common + ["--sleep", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Too few models" in r.stderr
 
 
 def test_two_shards_of_the_cpp_program_hand_over_to_rank_0(oracle, tmp_path):
