@@ -1695,12 +1695,15 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 // ABL: ablation bits of k_loop_256_skip for the tower (diagnostic builds); bit 8 = stamp s_memtime / s_memrealtime around the tower
 // into a.dbg (the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back item 6) - no output depends on the stamps.
 // TT = 1: compact tap table + ring loop (k_loop_256_ring): the form for 18 row tiles (6x6, 8 boards); needs PERM and 16 % P == 0.
-template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0, int TT = 0>
-__global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
+// NW = 4: four waves of 64 output channels, one per SIMD (A/B form, TZ_NET_W4=1): every activation fragment read from LDS feeds four
+// MFMAs instead of two; a wave then owns 208 accumulator registers on 5x5 and nothing fills its gaps.
+template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0, int TT = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
     static_assert(!SP || sizeof(ET) == 2, "split precision runs on fp16 halves");
-    constexpr int RN = 2, TAPS = 9, LAYOUT = 1, NT = 512;
+    constexpr int RN = 16 / NW, TAPS = 9, LAYOUT = 1, NT = NW * 64;
+    static_assert((NW == 8 || NW == 4) && (NW == 8 || SP == 0), "four waves: the fp16 / bf16 form only");
     typedef RowMap<NB, P, PERM> RM;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
@@ -1782,7 +1785,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         }
     } else {   // the per-tap fragment base addresses of a lane, once for all layers (read after the next barrier): wave w computes
         // taps w and w + 8
-        for (int tap = wave; tap < TAPS; tap += 8) {
+        for (int tap = wave; tap < TAPS; tap += NW) {
             int tb[RT];
             if constexpr (PERM) tap_bases_map<NB, P, true, LAYOUT>(tap, lr, q, ZROW, tb);
             else tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
@@ -1796,7 +1799,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
     };
     int obase[RN];
 #pragma unroll
-    for (int j = 0; j < RN; j++) obase[j] = wave * PLANE + lr * LDS_ROWB + lds_piece(lr, j * 2 + (q >> 1)) + (q & 1) * 8;
+    for (int j = 0; j < RN; j++) obase[j] = ((ct0 + j) >> 1) * PLANE + lr * LDS_ROWB + lds_piece(lr, ((ct0 + j) & 1) * 2 + (q >> 1)) + (q & 1) * 8;   // channels 16 (ct0 + j) + 4 q ..: plane of 32, piece of 8
     // SP = 2: where the lane's four channels (16 * (2 wave + j) + 4 q ..) sit in the FP8 hi plane: plane 8 + wave / 2 of 64 channels,
     // piece 2 (wave & 1) + j, byte 4 q; the lo and remainder planes are 4 and 8 planes further
     int obase8[RN];
@@ -2099,11 +2102,11 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
         // four rows per step: the 64-lane reductions of a row are a chain of six dependent cross-lane moves, four rows
         // give the pipeline four independent chains (same reduction tree per row, so the same bits)
         constexpr int HU = 4;
-        for (int row0 = wave; row0 < HROWS; row0 += 8 * HU) {
+        for (int row0 = wave; row0 < HROWS; row0 += NW * HU) {
             float dv[HU], du[HU];
 #pragma unroll
             for (int u = 0; u < HU; u++) {
-                const int row = min(row0 + 8 * u, HROWS - 1);
+                const int row = min(row0 + NW * u, HROWS - 1);
                 const int haddr = hplane * PLANE + row * LDS_ROWB + lds_piece(row, hpiece) + hhalf * 8;
                 const ex4 xv = *reinterpret_cast<const ex4*>(lds + haddr);
                 float xf[4];
@@ -2138,7 +2141,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             if (lane == 0) {
 #pragma unroll
                 for (int u = 0; u < HU; u++) {
-                    const int row = row0 + 8 * u;
+                    const int row = row0 + NW * u;
                     if (row < HROWS) {
                         const float a = dv[u] + bv, b = du[u] + bu;
                         hscratch[row] = a > 0.f ? a : 0.f;
@@ -2148,7 +2151,7 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             }
         }
         __syncthreads();
-        for (int pos = wave; pos < P; pos += 8) {
+        for (int pos = wave; pos < P; pos += NW) {
             if (pos0 + pos >= count) break;
             float sv = 0.f, su = 0.f;
             for (int px = lane; px < NN; px += 64) {
@@ -2167,22 +2170,23 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
             }
         }
     }
-    // ---- policy conv: 16*RNP output channels per wave, fp32 out
+    // ---- policy conv: 16*RNPW output channels per wave, fp32 out
     {
-        const int ctp = wave * RNP;
+        constexpr int RNPW = RNP * 8 / NW;   // column tiles of a wave
+        const int ctp = wave * RNPW;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_pol), 0, TAPS * 8 * 8 * RNP * 1024, 0x00020000);
-        f32x4 pacc[RT][RNP];
+        f32x4 pacc[RT][RNPW];
 #pragma unroll
-        for (int j = 0; j < RNP; j++) {
+        for (int j = 0; j < RNPW; j++) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias_pol + (ctp + j) * 16 + q * 4);
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) pacc[rt][j] = b4;
         }
         if constexpr (SP == 2) {
             const __amdgpu_buffer_rsrc_t rs8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.w_pol8), 0, TAPS * 2 * 8 * RNP * 2 * 2048, 0x00020000);
-            f32x4 paccc[RT][RNP];
+            f32x4 paccc[RT][RNPW];
 #pragma unroll
-            for (int j = 0; j < RNP; j++)
+            for (int j = 0; j < RNPW; j++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) paccc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             auto wlp = [&](int tap, int kc, int j) -> ex8 {
@@ -2195,28 +2199,28 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs8, lane * 32 + 16, frag * 2048, 0));
                 return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             };
-            k_loop_c8<NB, P, PERM, RNP, PLANE>(lds, tap_table, lane, pacc, paccc, wlp, wlp8);
+            k_loop_c8<NB, P, PERM, RNPW, PLANE>(lds, tap_table, lane, pacc, paccc, wlp, wlp8);
             const float cs = a.c8_scales[a.nlayers];
 #pragma unroll
-            for (int j = 0; j < RNP; j++)
+            for (int j = 0; j < RNPW; j++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) pacc[rt][j][k] += paccc[rt][j][k] * cs;
         } else if constexpr (SP) {
             const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_pol_lo), 0, TAPS * 8 * 8 * RNP * 1024, 0x00020000);
-            f32x4 paccc[RT][RNP];
+            f32x4 paccc[RT][RNPW];
 #pragma unroll
-            for (int j = 0; j < RNP; j++)
+            for (int j = 0; j < RNPW; j++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) paccc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             auto wlp2 = [&](int tap, int kc, int j, int part) -> ex8 {
                 const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(part ? rsl : rs, lane16, frag * 1024, 0));
             };
-            k_loop_split<NB, P, PERM, RNP, PLANE>(lds, tap_table, lane, pacc, paccc, wlp2);
+            k_loop_split<NB, P, PERM, RNPW, PLANE>(lds, tap_table, lane, pacc, paccc, wlp2);
 #pragma unroll
-            for (int j = 0; j < RNP; j++)
+            for (int j = 0; j < RNPW; j++)
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -2226,12 +2230,12 @@ __global__ __launch_bounds__(512, 2) void net_mfma_kernel(NetArgs a) {
                 const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0));
             };
-            if constexpr (TT) k_loop_256_ring<NB, P, RNP, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, pacc, wlp);
-            else if constexpr (PERM) k_loop_256_skip<NB, P, RNP, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
-            else k_loop_256<NB, RT, RNP, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+            if constexpr (TT) k_loop_256_ring<NB, P, RNPW, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, pacc, wlp);
+            else if constexpr (PERM) k_loop_256_skip<NB, P, RNPW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+            else k_loop_256<NB, RT, RNPW, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
         }
 #pragma unroll
-        for (int j = 0; j < RNP; j++) {
+        for (int j = 0; j < RNPW; j++) {
             const int cbase = (ctp + j) * 16 + q * 4;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
@@ -3026,13 +3030,13 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0>
+template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0, int NW = 8>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
     constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * (SP == 2 ? sizeof(uint16_t) : sizeof(int));
     constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP == 2 ? 20 : SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
     static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
-    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT>;
+    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT, NW>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
     int attr_dev = 0;
     TZ_HIP(hipGetDevice(&attr_dev));
@@ -3041,7 +3045,7 @@ int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((max_positions + P - 1) / P), dim3(512), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3((max_positions + P - 1) / P), dim3(NW * 64), smem, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("net launch: ") + hipGetErrorString(e));
     return TZ_OK;
@@ -3108,6 +3112,9 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
         case 5:
 #ifdef TZ_ABLATIONS   // A/B: the 5x5 kernel on the compact tap table + fragment ring of the 6x6 form (TZ_NET_TT=1)
             if (sq && getenv("TZ_NET_TT") && atoi(getenv("TZ_NET_TT")) == 1) return launch_net<5, 1, ET, true, 8, 0, 0, 1>(a, max_positions, st);
+#endif
+#ifdef TZ_ABLATIONS   // A/B: four waves of 64 channels, one per SIMD (TZ_NET_W4=1)
+            if (sq && getenv("TZ_NET_W4") && atoi(getenv("TZ_NET_W4")) == 1) return launch_net<5, 1, ET, true, 8, 0, 0, 0, 4>(a, max_positions, st);
 #endif
             return sq ? launch_net<5, 1, ET, true>(a, max_positions, st) : launch_net<5, 1, ET, false>(a, max_positions, st);
         case 6:
