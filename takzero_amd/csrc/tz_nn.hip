@@ -1526,9 +1526,11 @@ __device__ __forceinline__ float c8_value(_Float16 hi, int l8, int r8, int k) {
 // bytes).  The operands run D items ahead of the MFMAs through a ring of D 32-byte slots, across tap boundaries (the next
 // tap's fragment addresses are read from the tap table two chunks before it starts); consecutive MFMAs never share an
 // accumulator (all tiles of one chunk or term, then the next).
-template <int NB, int P, bool PERM, int RNX, int PLANE, typename TapT, typename WL, typename WL8>
+// FAIR (A/B): once per tap a wave posts its progress in LDS and lowers its priority while it is ahead of the SIMD's other wave
+template <int NB, int P, bool PERM, int RNX, int PLANE, int FAIR = 0, typename TapT, typename WL, typename WL8>
 __device__ __forceinline__ void k_loop_c8(const unsigned char* lds, const TapT* tap_table, int lane,
-                                          f32x4 (&accm)[RowMap<NB, P, PERM>::RT][RNX], f32x4 (&accc)[RowMap<NB, P, PERM>::RT][RNX], WL wl, WL8 wl8) {
+                                          f32x4 (&accm)[RowMap<NB, P, PERM>::RT][RNX], f32x4 (&accc)[RowMap<NB, P, PERM>::RT][RNX], WL wl, WL8 wl8,
+                                          int* fair_slots = nullptr, int fair_wave = 0, int fair_step0 = 0) {
     typedef Elem<_Float16> E;
     typedef f16x8 ex8;
     typedef RowMap<NB, P, PERM> RM;
@@ -1592,6 +1594,13 @@ __device__ __forceinline__ void k_loop_c8(const unsigned char* lds, const TapT* 
         constexpr unsigned NEXT = tap + 1 < TAPS ? RM::tap_tile_mask(tap + 1 < TAPS ? tap + 1 : tap) : 0u;
         constexpr int NA = __builtin_popcount(NOW), NI = 12 * NA;
         static_assert(NA >= 1 && 12 * __builtin_popcount(NEXT ? NEXT : 1u) >= D, "ring depth");
+        if constexpr (FAIR != 0) {
+            const int step = fair_step0 + tap;
+            fair_slots[fair_wave] = step;
+            const int other = __builtin_amdgcn_readfirstlane(fair_slots[fair_wave ^ 4]);
+            if (other < step) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(3);
+        }
         auto item = [&](auto u_c) {
             constexpr int u = decltype(u_c)::value;
             constexpr int seg = u < 4 * NA ? 0 : u < 6 * NA ? 1 : u < 10 * NA ? 2 : 3;
@@ -1997,7 +2006,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc8, lane * 32 + 16, frag * 2048, 0));
                 return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             };
-            k_loop_c8<NB, P, PERM, RN, PLANE>(lds, tap_table, lane, acc, accc, wl, wl8);
+            k_loop_c8<NB, P, PERM, RN, PLANE, ((ABL & 32) ? 1 : 0)>(lds, tap_table, lane, acc, accc, wl, wl8, reinterpret_cast<int*>(hscratch), wave, layer * 9);
         } else if constexpr (SP) {
             auto wl2 = [&](int tap, int kc, int j, int part) -> ex8 {
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
@@ -3187,6 +3196,8 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     if (net->precision == TZ_PREC_F16C8) {   // same workgroups as the split form (20 planes instead of 16: the tap table halves)
 #ifdef TZ_ABLATIONS
         if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 16) return launch_net<5, 1, _Float16, true, 4, 2, 16>(a, max_positions, st);
+        if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 32) return launch_net<5, 1, _Float16, true, 4, 2, 32>(a, max_positions, st);
+        if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 48) return launch_net<5, 1, _Float16, true, 4, 2, 48>(a, max_positions, st);
 #endif
         // small batches (the Agent surface at the reference's batch of 128): one or two boards per workgroup, as in the fp16 form
         if (net->n == 5 && net_small_p(max_positions) == 1) return launch_net<5, 1, _Float16, false, 1, 2>(a, max_positions, st);
