@@ -373,6 +373,9 @@ def main():
                                # thirds on FP8 MFMAs at 5 PFLOP/s -> 3.75 PFLOP/s for the mix
                                "issued_frac_of_mfma_mix_peak": (issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 /
                                                                 (3750.0 if args.precision == "f16c8" else PEAK_BF16_TFLOPS) if FUSED_MODE == 2 else None),
+                               # the chip's own best case beside the sheet figure: a bare loop of independent fp16 MFMAs with every operand in
+                               # registers reaches 1.99 PFLOP/s (power-limited clock; tools/mfma_f8_probe.hip, profiles/r02_mfma_f8_probe.txt)
+                               "bare_mfma_loop_tflops": {"value": 1986.0, "source": "stored figure: profiles/r02_mfma_f8_probe.txt (tools/mfma_f8_probe.hip, mode 0)"},
                                "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
                                "positions_per_launch": per_launch_positions}
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
