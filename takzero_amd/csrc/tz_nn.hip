@@ -1348,8 +1348,19 @@ __device__ __forceinline__ void k_loop_256_ring(const unsigned char* lds, const 
 // are exact in fp32, so the layer is an fp32 convolution of 22-bit operands.  Same k order, tap table, row maps and
 // skipped (tap, tile) pairs as k_loop_256_skip; weight fragments one k-step ahead (a k-step is 6 MFMAs per row tile).
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
-template <int NB, int P, bool PERM, int RNX, int PLANE, typename WL>
-__device__ __forceinline__ void k_loop_split(const unsigned char* lds, const int* tap_table, int lane,
+// A tap-table entry as a fragment address.  32- and 16-bit entries are the address; 8-bit entries (6x6 with 4 boards in a split
+// precision: the table has to fit beside 16 planes) are the image row, and the lane's 16-byte piece follows from the row
+template <typename TapT>
+__device__ __forceinline__ int tap_addr(TapT e, int lane) {
+    if constexpr (sizeof(TapT) == 1) {
+        const int row = e;
+        return row * LDS_ROWB + lds_piece(row, lane >> 4);
+    } else {
+        return (int)e;
+    }
+}
+template <int NB, int P, bool PERM, int RNX, int PLANE, typename TapT, typename WL>
+__device__ __forceinline__ void k_loop_split(const unsigned char* lds, const TapT* tap_table, int lane,
                                              f32x4 (&accm)[RowMap<NB, P, PERM>::RT][RNX], f32x4 (&accc)[RowMap<NB, P, PERM>::RT][RNX], WL wl) {
     typedef Elem<_Float16> E;
     typedef f16x8 ex8;
@@ -1367,7 +1378,7 @@ __device__ __forceinline__ void k_loop_split(const unsigned char* lds, const int
         constexpr unsigned M0 = RM::tap_tile_mask(0);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
-            if ((M0 >> rt) & 1) abase[rt] = tap_table[rt * 64 + lane];
+            if ((M0 >> rt) & 1) abase[rt] = tap_addr(tap_table[rt * 64 + lane], lane);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
             if ((M0 >> rt) & 1) {
@@ -1398,7 +1409,7 @@ __device__ __forceinline__ void k_loop_split(const unsigned char* lds, const int
             if (kc == 7) {
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)
-                    if ((NEXT >> rt) & 1) abase[rt] = tap_table[((tap + 1) * RT + rt) * 64 + lane];
+                    if ((NEXT >> rt) & 1) abase[rt] = tap_addr(tap_table[((tap + 1) * RT + rt) * 64 + lane], lane);
             }
             if (kc == 4) {
 #pragma unroll
@@ -1535,7 +1546,7 @@ __device__ __forceinline__ void k_loop_c8(const unsigned char* lds, const TapT* 
     typedef f16x8 ex8;
     typedef RowMap<NB, P, PERM> RM;
     constexpr int TAPS = 9, RT = RM::RT, D = 4;
-    static_assert(7 * PLANE < 65536, "plane offsets of a ring load must fit a ds_read immediate");
+    // plane offsets up to 7 planes: ds_read immediates on 5x5 (7 x 7680 B); the 6x6 four-board image (9728 B planes) pays an add on the last plane
     ex8 bq[4][RNX];
 #pragma unroll
     for (int j = 0; j < RNX; j++) {
@@ -1580,7 +1591,7 @@ __device__ __forceinline__ void k_loop_c8(const unsigned char* lds, const TapT* 
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
             if ((M0 >> rt) & 1) {
-                abase[rt] = tap_table[rt * 64 + lane];
+                abase[rt] = tap_addr(tap_table[rt * 64 + lane], lane);
                 abase8[rt] = abase[rt] + 8 * PLANE;
             }
         load_item(IntC<(int)M0>{}, IntC<0>{}, abase, abase8, rg[0]);
@@ -1635,7 +1646,7 @@ __device__ __forceinline__ void k_loop_c8(const unsigned char* lds, const TapT* 
                 if (kc == 6) {   // the next tap's fragment addresses
 #pragma unroll
                     for (int r = 0; r < RT; r++)
-                        if ((NEXT >> r) & 1) abn[r] = tap_table[((tap + 1) * RT + r) * 64 + lane];
+                        if ((NEXT >> r) & 1) abn[r] = tap_addr(tap_table[((tap + 1) * RT + r) * 64 + lane], lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1716,9 +1727,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     typedef RowMap<NB, P, PERM> RM;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
-    constexpr int NPL = SP == 2 ? 20 : SP ? 16 : 8, LO = 8 * PLANE;   // image planes; byte offset of the lo half of a plane
-    typedef typename std::conditional<SP == 2, uint16_t, int>::type tap_t;   // a fragment address inside a plane fits 16 bits
+    // 6x6 with 4 boards in a split precision: 16 planes and a table of 8-bit rows is what fits the 160 KB; the FP8-correction form then
+    // has no remainder planes and carries a block input as hi + one FP8 byte (15 bits: twice the logit error, tools/fp8_correction_study.py)
+    constexpr bool ROWTAB = SP != 0 && NB == 6 && P == 4;
+    constexpr bool R8 = SP == 2 && NB != 6;   // every 6x6 form alike, so that a position's outputs do not depend on the batch it came in
+    constexpr int NPL = SP == 2 ? (R8 ? 20 : 16) : SP ? 16 : 8, LO = 8 * PLANE;   // image planes; byte offset of the lo half of a plane
+    typedef typename std::conditional<ROWTAB, uint8_t, typename std::conditional<SP == 2, uint16_t, int>::type>::type tap_t;
     static_assert(SP != 2 || PLANE < 65536, "16-bit tap table");
+    static_assert(!ROWTAB || LROWS <= 256, "8-bit tap table");
     constexpr int LAYER_FRAGS = TAPS * 8 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* hscratch = reinterpret_cast<float*>(lds + NPL * PLANE);  // [2][RT*16] head pre-activations
@@ -1799,12 +1815,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             if constexpr (PERM) tap_bases_map<NB, P, true, LAYOUT>(tap, lr, q, ZROW, tb);
             else tap_bases_rc<NB, RT, TAPS, LAYOUT>(tap, lr, q, ROWS, ZROW, tb);
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = (tap_t)tb[rt];
+            for (int rt = 0; rt < RT; rt++) tap_table[(tap * RT + rt) * 64 + lane] = (tap_t)(ROWTAB ? tb[rt] / LDS_ROWB : tb[rt]);
         }
     }
     auto ta = [&](int tap, int rt) -> int {   // the lane's fragment base address of row tile rt under `tap`
         if constexpr (TT) return tap_table[(tap * RT + rt) * RM::PPT + tslot] + lane_const;
-        else return tap_table[(tap * RT + rt) * 64 + lane];
+        else return tap_addr(tap_table[(tap * RT + rt) * 64 + lane], lane);
     };
     int obase[RN];
 #pragma unroll
@@ -1818,11 +1834,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     auto store_c8 = [&](const f32x4& v, int j, int rt, bool block_output) {
         f16x4 hi;
         int h8, l8, r8;
-        c8_parts(v, hi, h8, l8, r8, block_output);
+        c8_parts(v, hi, h8, l8, r8, R8 && block_output);
         *reinterpret_cast<f16x4*>(lds + obase[j] + rt * 16 * LDS_ROWB) = hi;
         *reinterpret_cast<int*>(lds + obase8[j] + rt * 16 * LDS_ROWB) = h8;
         *reinterpret_cast<int*>(lds + obase8[j] + 4 * PLANE + rt * 16 * LDS_ROWB) = l8;
-        if (block_output) *reinterpret_cast<int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB) = r8;
+        if (R8 && block_output) *reinterpret_cast<int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB) = r8;
     };
 
     f32x4 acc[RT][RN];
@@ -2048,7 +2064,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                     if (to_second) {   // the block input, carried to 19 bits, starts the second conv's accumulator
                         const f16x4 xh = *reinterpret_cast<const f16x4*>(slot);
                         const int xl8 = *reinterpret_cast<const int*>(lds + obase8[j] + 4 * PLANE + rt * 16 * LDS_ROWB);
-                        const int xr8 = *reinterpret_cast<const int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB);
+                        const int xr8 = R8 ? *reinterpret_cast<const int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB) : 0;
 #pragma unroll
                         for (int k = 0; k < 4; k++) acc[rt][j][k] = c8_value(xh[k], xl8, xr8, k) + b4[k];
                     }
@@ -2123,7 +2139,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 for (int k = 0; k < 4; k++) xf[k] = (float)xv[k];
                 if constexpr (SP == 2) {   // channels 4 lane ..: FP8 plane lane / 16, piece (lane & 15) / 4, byte 4 (lane & 3)
                     const int h8addr = (12 + (lane >> 4)) * PLANE + row * LDS_ROWB + lds_piece(row, (lane & 15) >> 2) + (lane & 3) * 4;
-                    const int xl8 = *reinterpret_cast<const int*>(lds + h8addr), xr8 = *reinterpret_cast<const int*>(lds + h8addr + 4 * PLANE);
+                    const int xl8 = *reinterpret_cast<const int*>(lds + h8addr), xr8 = R8 ? *reinterpret_cast<const int*>(lds + h8addr + 4 * PLANE) : 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) xf[k] = c8_value(xv[k], xl8, xr8, k);
                 } else if constexpr (SP) {
@@ -3042,8 +3058,9 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
 template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0, int NW = 8>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
-    constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * (SP == 2 ? sizeof(uint16_t) : sizeof(int));
-    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP == 2 ? 20 : SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
+    constexpr bool ROWTAB = SP != 0 && NB == 6 && P == 4;   // as in the kernel: 8-bit table, no remainder planes
+    constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * (ROWTAB ? 1 : SP == 2 ? sizeof(uint16_t) : sizeof(int));
+    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP == 2 ? (NB == 6 ? 16 : 20) : SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
     static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
     auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT, NW>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
@@ -3189,7 +3206,9 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
             case 3: return launch_net<3, 1, _Float16, false, 8, 1>(a, max_positions, st);
             case 4: return launch_net<4, 1, _Float16, false, 6, 1>(a, max_positions, st);
             case 5: return launch_net<5, 1, _Float16, true, 4, 1>(a, max_positions, st);
-            case 6: return launch_net<6, 2, _Float16, false, 2, 1>(a, max_positions, st);
+            case 6:   // from 1024 positions on: 4 boards, square-major rows (12 of 81 pairs skipped), table of 8-bit rows
+                if (net_square_major() && max_positions >= 1024) return launch_net<6, 2, _Float16, true, 4, 1>(a, max_positions, st);
+                return launch_net<6, 2, _Float16, false, 2, 1>(a, max_positions, st);
         }
         return tz_fail(TZ_EINVAL, "net: unsupported board size");
     }
@@ -3206,7 +3225,9 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
             case 3: return launch_net<3, 1, _Float16, false, 8, 2>(a, max_positions, st);
             case 4: return launch_net<4, 1, _Float16, false, 6, 2>(a, max_positions, st);
             case 5: return launch_net<5, 1, _Float16, true, 4, 2>(a, max_positions, st);
-            case 6: return launch_net<6, 2, _Float16, false, 2, 2>(a, max_positions, st);
+            case 6:   // the same; at 4 boards the block input is carried as hi + one FP8 byte (no room for the remainder planes)
+                if (net_square_major() && max_positions >= 1024) return launch_net<6, 2, _Float16, true, 4, 2>(a, max_positions, st);
+                return launch_net<6, 2, _Float16, false, 2, 2>(a, max_positions, st);
         }
         return tz_fail(TZ_EINVAL, "net: unsupported board size");
     }

@@ -208,6 +208,25 @@ def test_forward_is_batch_composition_independent(oracle, prec, n):
         assert np.array_equal(pol[perm], pol2) and np.array_equal(val[perm], val2) and np.array_equal(ube[perm], ube2), count
 
 
+@pytest.mark.parametrize("prec", [3, 4])
+def test_workgroup_forms_of_the_split_precisions_on_6x6_give_the_same_bits(oracle, prec):
+    """6x6 in a split precision: 2 boards per workgroup (board-major rows) below 1024 positions, 4 boards (square-major rows, 12 of
+    81 (tap, tile) pairs skipped, tap table of 8-bit rows) from there on - the same bits for a position either way."""
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    net = A.Net(arch=A.ARCH_NET6_SIMHASH, precision=prec)
+    net.load_tensors(W.init_weights(W.ARCH_NET6_SIMHASH, seed=9))
+    base = O.states_array(random_positions(oracle, O, 6, 4, 64, 23))
+    states = np.concatenate([base] * 18)[:1100]
+    big = net.forward_raw(states)
+    for count in (1027, 300, 5):
+        part = net.forward_raw(states[:count])
+        for x, y in zip(big, part):
+            assert np.array_equal(x[:count], y), (prec, count)
+    net.close()
+
+
 @pytest.mark.parametrize("prec", [2, 4])
 def test_workgroup_forms_give_the_same_bits(oracle, prec):
     """Small batches run on 1- and 2-board workgroups (board-major rows), large ones on 8 (fp16) or 4 (fp16 + FP8 corrections)
