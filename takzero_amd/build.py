@@ -18,6 +18,7 @@ UNITS = [
     ("tz_tree.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_capi.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_nn.hip", []),
+    ("tz_nn_split.hip", []),          # includes tz_nn.hip with TZ_NN_SPLIT_TU: the split-precision kernels, compiled in parallel
     ("tz_learn.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function",
@@ -54,8 +55,10 @@ def build(force=False, verbose=False, ablations=None):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers) or (force_nn and src == "tz_nn.hip"):
-            cmd = [hipcc] + COMMON + extra + (["-DTZ_ABLATIONS"] if ablations and src == "tz_nn.hip" else []) + ["-x", "hip", "-c", s, "-o", o]
+        nn = src in ("tz_nn.hip", "tz_nn_split.hip")
+        deps = [s] + headers + ([os.path.join(CSRC, "tz_nn.hip")] if nn else [])
+        if force or _stale(o, deps) or (force_nn and nn):
+            cmd = [hipcc] + COMMON + extra + (["-DTZ_ABLATIONS"] if ablations and nn else []) + ["-x", "hip", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

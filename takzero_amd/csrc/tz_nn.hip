@@ -26,6 +26,8 @@
 #include <cstring>
 #include <map>
 
+int tz_nn_launch_split(int sp, int n, const void* net_args, int max_positions, hipStream_t st);   // the second translation unit
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2273,6 +2275,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     }
 }
 
+#ifndef TZ_NN_SPLIT_TU   // the second translation unit (tz_nn_split.hip) holds the split-precision instantiations of the net kernel only
 // ---------------------------------------------------------------------------------------------
 // fp32 validation path: one thread per (row, output channel); weights [tap][cin][cout].
 template <int NB>
@@ -3046,6 +3049,8 @@ int tower_bf16(tz_net* net, const void* in, void* out, const int32_t* count_dev,
     return tz_fail(TZ_EINVAL, "tower: unsupported board size");
 }
 
+#endif  // TZ_NN_SPLIT_TU
+
 int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fused tower only; 0: one launch per conv
     static int mode = -1;
     if (mode < 0) {
@@ -3098,6 +3103,47 @@ int net_small_p(int max_positions) {
     if (full) return 0;
     return max_positions <= 256 ? 1 : max_positions <= 512 ? 2 : max_positions <= 1024 ? 4 : 0;
 }
+
+#ifdef TZ_NN_SPLIT_TU
+}  // namespace
+
+// The split-precision launches (TZ_PREC_F16X2: sp = 1, TZ_PREC_F16C8: sp = 2) live in their own translation unit so that the two
+// compile side by side (tz_nn_split.hip includes this file with TZ_NN_SPLIT_TU defined); `net_args` is the caller's NetArgs.
+int tz_nn_launch_split(int sp, int n, const void* net_args, int max_positions, hipStream_t st) {
+    const NetArgs& a = *static_cast<const NetArgs*>(net_args);
+    if (sp == 1) {
+        // split precision: hi and lo planes share the 160 KB, so half the boards per workgroup (5x5: 4 boards, square-major
+        // rows, 14 of 63 (tap, tile) pairs skipped; the other sizes board-major)
+        switch (n) {
+            case 3: return launch_net<3, 1, _Float16, false, 8, 1>(a, max_positions, st);
+            case 4: return launch_net<4, 1, _Float16, false, 6, 1>(a, max_positions, st);
+            case 5: return launch_net<5, 1, _Float16, true, 4, 1>(a, max_positions, st);
+            case 6:   // from 1024 positions on: 4 boards, square-major rows (12 of 81 pairs skipped), table of 8-bit rows
+                if (net_square_major() && max_positions >= 1024) return launch_net<6, 2, _Float16, true, 4, 1>(a, max_positions, st);
+                return launch_net<6, 2, _Float16, false, 2, 1>(a, max_positions, st);
+        }
+        return tz_fail(TZ_EINVAL, "net: unsupported board size");
+    }
+    // fp16 + FP8 corrections: same workgroups as the split form (20 planes instead of 16: the tap table halves)
+#ifdef TZ_ABLATIONS
+    if (n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 16) return launch_net<5, 1, _Float16, true, 4, 2, 16>(a, max_positions, st);
+    if (n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 32) return launch_net<5, 1, _Float16, true, 4, 2, 32>(a, max_positions, st);
+    if (n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 48) return launch_net<5, 1, _Float16, true, 4, 2, 48>(a, max_positions, st);
+#endif
+    // small batches (the Agent surface at the reference's batch of 128): one or two boards per workgroup, as in the fp16 form
+    if (n == 5 && net_small_p(max_positions) == 1) return launch_net<5, 1, _Float16, false, 1, 2>(a, max_positions, st);
+    if (n == 5 && net_small_p(max_positions) == 2) return launch_net<5, 1, _Float16, false, 2, 2>(a, max_positions, st);
+    switch (n) {
+        case 3: return launch_net<3, 1, _Float16, false, 8, 2>(a, max_positions, st);
+        case 4: return launch_net<4, 1, _Float16, false, 6, 2>(a, max_positions, st);
+        case 5: return launch_net<5, 1, _Float16, true, 4, 2>(a, max_positions, st);
+        case 6:   // the same; on 6x6 the block input is carried as hi + one FP8 byte (no room for the remainder planes)
+            if (net_square_major() && max_positions >= 1024) return launch_net<6, 2, _Float16, true, 4, 2>(a, max_positions, st);
+            return launch_net<6, 2, _Float16, false, 2, 2>(a, max_positions, st);
+    }
+    return tz_fail(TZ_EINVAL, "net: unsupported board size");
+}
+#else   // the first translation unit: everything else
 
 bool net_p6_four() {
     static const bool four = getenv("TZ_NET_P6") && !strcmp(getenv("TZ_NET_P6"), "4");
@@ -3199,38 +3245,7 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
         net->dbg_groups = (max_positions + (prec_is_split(net->precision) ? 3 : 7)) / (prec_is_split(net->precision) ? 4 : 8);
     }
 #endif
-    if (net->precision == TZ_PREC_F16X2) {
-        // split precision: hi and lo planes share the 160 KB, so half the boards per workgroup (5x5: 4 boards, square-major
-        // rows, 14 of 63 (tap, tile) pairs skipped; the other sizes board-major)
-        switch (net->n) {
-            case 3: return launch_net<3, 1, _Float16, false, 8, 1>(a, max_positions, st);
-            case 4: return launch_net<4, 1, _Float16, false, 6, 1>(a, max_positions, st);
-            case 5: return launch_net<5, 1, _Float16, true, 4, 1>(a, max_positions, st);
-            case 6:   // from 1024 positions on: 4 boards, square-major rows (12 of 81 pairs skipped), table of 8-bit rows
-                if (net_square_major() && max_positions >= 1024) return launch_net<6, 2, _Float16, true, 4, 1>(a, max_positions, st);
-                return launch_net<6, 2, _Float16, false, 2, 1>(a, max_positions, st);
-        }
-        return tz_fail(TZ_EINVAL, "net: unsupported board size");
-    }
-    if (net->precision == TZ_PREC_F16C8) {   // same workgroups as the split form (20 planes instead of 16: the tap table halves)
-#ifdef TZ_ABLATIONS
-        if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 16) return launch_net<5, 1, _Float16, true, 4, 2, 16>(a, max_positions, st);
-        if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 32) return launch_net<5, 1, _Float16, true, 4, 2, 32>(a, max_positions, st);
-        if (net->n == 5 && getenv("TZ_NET_ABL") && atoi(getenv("TZ_NET_ABL")) == 48) return launch_net<5, 1, _Float16, true, 4, 2, 48>(a, max_positions, st);
-#endif
-        // small batches (the Agent surface at the reference's batch of 128): one or two boards per workgroup, as in the fp16 form
-        if (net->n == 5 && net_small_p(max_positions) == 1) return launch_net<5, 1, _Float16, false, 1, 2>(a, max_positions, st);
-        if (net->n == 5 && net_small_p(max_positions) == 2) return launch_net<5, 1, _Float16, false, 2, 2>(a, max_positions, st);
-        switch (net->n) {
-            case 3: return launch_net<3, 1, _Float16, false, 8, 2>(a, max_positions, st);
-            case 4: return launch_net<4, 1, _Float16, false, 6, 2>(a, max_positions, st);
-            case 5: return launch_net<5, 1, _Float16, true, 4, 2>(a, max_positions, st);
-            case 6:   // the same; at 4 boards the block input is carried as hi + one FP8 byte (no room for the remainder planes)
-                if (net_square_major() && max_positions >= 1024) return launch_net<6, 2, _Float16, true, 4, 2>(a, max_positions, st);
-                return launch_net<6, 2, _Float16, false, 2, 2>(a, max_positions, st);
-        }
-        return tz_fail(TZ_EINVAL, "net: unsupported board size");
-    }
+    if (prec_is_split(net->precision)) return tz_nn_launch_split(net->precision == TZ_PREC_F16C8 ? 2 : 1, net->n, &a, max_positions, st);   // tz_nn_split.hip
     if (net->precision == TZ_PREC_F16) return net_fused_et<_Float16>(net, a, max_positions, st);
     return net_fused_et<__bf16>(net, a, max_positions, st);
 }
@@ -4280,3 +4295,4 @@ int tz_net_forward_raw(tz_net* net, int batch, const tz_state* states, float* po
 }
 
 }  // extern "C"
+#endif  // TZ_NN_SPLIT_TU
