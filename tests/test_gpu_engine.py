@@ -63,6 +63,39 @@ def test_engine_matches_oracle_search_with_same_net(oracle, arch, n, blocks, pre
     assert gpu.counters() == ora.counters()
 
 
+def test_gumbel_search_at_trained_scale_agrees_with_the_fp32_path():
+    """The reference's current self-play search - Gumbel sequential halving, 64 sampled actions, budget 768 - reads the logits
+    directly (gumbel + logit picks the candidates, then sigma(q) + logit ranks them), so it is the search most exposed to logit
+    error.  Same positions, same Gumbel noise, weights at a trained net's logit scale: the action chosen under each arithmetic against
+    the one chosen under the fp32 validation network, and the visit counts at the root.  The two arithmetics that hold the 1e-3
+    logit tolerance choose the same action in (nearly) every game; the fp16 default is reported."""
+    A = require_gpu()
+    from takzero_amd import precision as P
+
+    n, B, k, budget = 5, 128, 64, 768
+    states = P.sample_positions(5, 4, B, seed=11, plies=10)
+    w = P.trained_scale_weights(A.ARCH_NET5, states[:64], seed=123)
+    rng = np.random.default_rng(3)
+    gumbel = rng.gumbel(size=(B, 512)).astype(np.float32)      # one draw per child, in possible_moves order
+    results = {}
+    for name in ("f32", "f16x2", "f16c8", "f16"):
+        net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_NAMES[name]).load_tensors(w)
+        mcts = A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 14)
+        mcts.set_positions(np.arange(B), states)
+        top = mcts.gumbel_sequential_halving(np.zeros(B, np.float32), k, budget, gumbel)
+        ch = mcts.root_children()
+        results[name] = (top.copy(), ch["visits"].astype(np.int64))
+        mcts.close()
+        net.close()
+    ref_top, ref_vis = results["f32"]
+    for name, min_same, min_identical in (("f16x2", 0.99, 0.97), ("f16c8", 0.98, 0.94), ("f16", 0.0, 0.0)):
+        top, vis = results[name]
+        same = float((top == ref_top).mean())
+        identical = float((vis == ref_vis).all(1).mean())
+        print("gumbel 64/768 at trained scale, %s vs f32 over %d games: same chosen action %.4f, identical root visit counts %.4f" % (name, B, same, identical))
+        assert same >= min_same and identical >= min_identical, name
+
+
 @pytest.mark.parametrize("scale,B,gates", [
     # (precision, min fraction of games with the same chosen move, min fraction with identical visit counts at every root child,
     #  max mean total-variation distance of the visit distributions)
