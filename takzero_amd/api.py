@@ -20,7 +20,11 @@ PREC_BF16, PREC_F32, PREC_F16, PREC_F16X2, PREC_F16C8 = 0, 1, 2, 3, 4
 # ~2e-4 *relative* of the fp32 graph through the 41 stacked convs (1.5e-4 absolute at the random-init logit scale of 0.2,
 # ~2e-3 at a trained net's logit scale of 10).  PREC_F16X2 ("f16x2") carries every operand as a hi / lo pair of halves
 # (three fp16 MFMAs per product, fp32 accumulate) and stays within the north star's absolute 1e-3 at trained scale, at
-# about 3x the MFMA work.  bf16 runs the fp16 kernels 5 % faster at 1e-3 .. 7e-3 (random-init scale).  TZ_PRECISION selects.
+# about 3x the MFMA work; PREC_F16C8 ("f16c8") keeps the fp16 product and takes the two correction products through FP8 (E4M3)
+# copies of the operands at twice the MFMA rate: 1.3e-4 at trained scale at 2.3x the fp16 kernel's time - the cheaper of the two
+# for a host that wants the reference's moves (under Gumbel 64 / 768 at trained scale the fp16 default picks the fp32 path's
+# action in 93 % of games, these two in all of them).  bf16 runs the fp16 kernels 5 % faster at 1e-3 .. 7e-3 (random-init
+# scale).  TZ_PRECISION selects.
 PREC_NAMES = {"bf16": PREC_BF16, "f16": PREC_F16, "f32": PREC_F32, "f16x2": PREC_F16X2, "f16c8": PREC_F16C8}
 PREC_DEFAULT = PREC_NAMES[os.environ.get("TZ_PRECISION", "f16")]
 AGENT_NET, AGENT_DUMMY, AGENT_SIMPLE = 0, 1, 2
