@@ -124,3 +124,29 @@ def test_fp16_storage_refuses_a_weight_outside_its_range_and_keeps_the_old_model
     for x, y in zip(before, after):
         assert np.array_equal(x, y)
     A.Net(arch=A.ARCH_TEST, n=5, precision=A.PREC_BF16, blocks=1).load_tensors(bad)
+
+
+@pytest.mark.parametrize("prec", ["f16x2", "f16c8"])
+def test_split_precisions_refuse_what_they_cannot_run_and_say_so(prec):
+    """The two split arithmetics live in the fused trunk launch only: a net without residual blocks is refused at the first forward
+    (TZ_EINVAL, message names both precisions), and like fp16 storage they refuse a folded weight outside fp16's range at load."""
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    oracle = O.load()
+    states = O.states_array(random_positions(oracle, O, 4, 4, 3, 2, max_ply=10))
+    net = A.Net(arch=A.ARCH_TEST, n=4, precision=A.PREC_NAMES[prec], blocks=0).load_tensors(W.init_weights(W.ARCH_TEST, n=4, blocks=0, seed=1))
+    with pytest.raises(A.TakzeroError, match="at least one residual block"):
+        net.forward_raw(states)
+    net.close()
+    w = W.init_weights(W.ARCH_TEST, n=4, blocks=1, seed=2)
+    good = A.Net(arch=A.ARCH_TEST, n=4, precision=A.PREC_NAMES[prec], blocks=1).load_tensors(w)
+    before = good.forward_raw(states)
+    bad = {k: v.copy() for k, v in w.items()}
+    name = next(k for k in bad if k.endswith("conv2d.weight") and "res_block" in k)
+    bad[name].flat[3] = 1.0e6
+    with pytest.raises(A.TakzeroError):
+        good.load_tensors(bad)
+    for x, y in zip(before, good.forward_raw(states)):
+        assert np.array_equal(x, y)
+    good.close()
