@@ -12,23 +12,21 @@ inline uint8_t tz_f32_to_e4m3(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
     const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
-    const float a = fabsf(f);
-    if (!(a == a)) return (uint8_t)(sign | 0x7f);
-    if (a >= 464.0f) return (uint8_t)(sign | 0x7e);   // 464 = halfway between 448 and the next step: everything above saturates
-    if (a < ldexpf(1.0f, -6)) {                       // subnormals: multiples of 2^-9 (and the smallest normal, code 8)
-        const int qs = (int)nearbyintf(ldexpf(a, 9)); // default rounding mode: to nearest even
-        return (uint8_t)(sign | qs);
+    uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint8_t)(sign | 0x7f);          // NaN
+    if (a >= 0x43e80000u) return (uint8_t)(sign | 0x7e);         // >= 464 = halfway between 448 and the next step (and inf): saturate
+    if (a < 0x3c800000u) {                                       // below 2^-6: multiples of 2^-9 (code 8 = the smallest normal)
+        float v;
+        memcpy(&v, &a, 4);
+        v = v * 512.0f + 8388608.0f;                             // 2^23: the add rounds v * 2^9 to an integer, to nearest even
+        uint32_t q;
+        memcpy(&q, &v, 4);
+        return (uint8_t)(sign | (q & 0x7fffffu));
     }
-    int e;
-    (void)frexpf(a, &e);                              // a = m * 2^e, m in [0.5, 1)  ->  a = 1.x * 2^(e-1)
-    int E = e - 1;
-    int q = (int)nearbyintf(ldexpf(a, 3 - E));        // 8 .. 16
-    if (q == 16) {
-        q = 8;
-        E++;
-    }
-    if (E > 8 || (E == 8 && q > 14)) return (uint8_t)(sign | 0x7e);
-    return (uint8_t)(sign | ((E + 7) << 3) | (q - 8));
+    a += 0x0007ffffu + ((a >> 20) & 1u);                         // round the mantissa to 3 bits, to nearest even; a carry bumps the exponent
+    const uint32_t e = (a >> 23) - 120u, m = (a >> 20) & 7u;     // exponent field: unbiased + 7
+    if (e > 15u || (e == 15u && m == 7u)) return (uint8_t)(sign | 0x7e);
+    return (uint8_t)(sign | (e << 3) | m);
 }
 
 inline float tz_e4m3_to_f32(uint8_t v) {
