@@ -350,8 +350,9 @@ def main():
             traffic = None   # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/)
             tpath = os.path.join(ROOT, "profiles", "tower_pmc_traffic.json")
             split = args.precision in ("f16x2", "f16c8")
-            if FUSED_MODE == 2 and args.games == GAMES and os.path.exists(tpath) and not split:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            if FUSED_MODE == 2 and args.games == GAMES and os.path.exists(tpath):
+                stored = json.load(open(tpath))
+                traffic = (stored.get(args.precision) or {}).get("hbm_bytes_per_launch") if split else stored.get("hbm_bytes_per_launch")
             kernel_name, rows, issued = KERNEL_NAME, "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS, ISSUED_FLOP_PER_LAUNCH_POS
             if split and FUSED_MODE == 2:
                 # 4 boards per workgroup (7 row tiles, 49 of 63 pairs issued) and three products per MAC: hi*hi on fp16 MFMAs, the two
