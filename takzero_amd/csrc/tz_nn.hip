@@ -24,7 +24,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <thread>
 
 int tz_nn_launch_split(int sp, int n, const void* net_args, int max_positions, hipStream_t st);   // the second translation unit
 
@@ -2769,13 +2772,40 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
     // the first conv of TZ_PREC_F16C8 is the split form too: its input planes are built in the kernel, its k-loop is 9 steps
     if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in, split || c8))) return rc;
     W.res.resize(2 * net->blocks);
-    for (int b = 0; b < net->blocks; b++)
-        for (int h = 0; h < 2; h++) {
-            const std::string p = "core.res_block_" + std::to_string(b) + (h ? ".b" : ".a");
-            if ((rc = get_tensor(m, p + ".conv2d.weight", (size_t)FILTERS * FILTERS * 9, w))) return rc;
-            if ((rc = bn_fold(m, p + ".batch_norm", FILTERS, scale, bias))) return rc;
-            if ((rc = build_layer(prec, 9, FILTERS, FILTERS, 256, w, scale, bias, nullptr, &W.res[2 * b + h], split, c8))) return rc;
-        }
+    {
+        // the tower's layers are independent (BatchNorm folding, fragment order, fp16 / FP8 conversion, upload: 9 ms each on one host
+        // thread): a hot reload stalls the self-play loop for as long as this takes, so they are spread over a few threads
+        const int nl = 2 * net->blocks;
+        const int workers = std::max(1, std::min(nl, std::min(16, (int)std::thread::hardware_concurrency())));
+        std::atomic<int> next{0}, failed{TZ_OK};
+        std::string first_error;
+        std::mutex mu;
+        auto work = [&]() {
+            if (hipSetDevice(net->device) != hipSuccess) {
+                failed = TZ_EDEVICE;
+                return;
+            }
+            std::vector<float> lw, lscale, lbias;
+            for (int l = next++; l < nl && failed == TZ_OK; l = next++) {
+                const std::string p = "core.res_block_" + std::to_string(l / 2) + ((l & 1) ? ".b" : ".a");
+                int r = get_tensor(m, p + ".conv2d.weight", (size_t)FILTERS * FILTERS * 9, lw);
+                if (!r) r = bn_fold(m, p + ".batch_norm", FILTERS, lscale, lbias);
+                if (!r) r = build_layer(prec, 9, FILTERS, FILTERS, 256, lw, lscale, lbias, nullptr, &W.res[l], split, c8);
+                if (r) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (failed == TZ_OK) {
+                        failed = r;
+                        first_error = tz_last_error();   // the error text is per thread: hand it to the caller's
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < workers; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        if (failed != TZ_OK) return tz_fail(failed, first_error.empty() ? "weights: a tower layer could not be built" : first_error);
+    }
     if (prec != TZ_PREC_F32 && net->blocks > 0) {  // the fused tower kernel reads all layers from one buffer
         const size_t layer_elems = (size_t)9 * 8 * 16 * 64 * 8, nl = W.res.size();
         TZ_HIP(hipMalloc(&W.tower_w, nl * layer_elems * 2));
