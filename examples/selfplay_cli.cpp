@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <string>
 
 #include "takzero_hip.h"
@@ -26,6 +27,10 @@ struct Reload {
     int rank = 0;
     long long stamp_s = -1, stamp_ns = -1, size = -1, inode = -1;
     int reloads = 0;
+    // --async-reload (one process, no communicator): a changed file is parsed and its device weights are built on another thread
+    // while the games go on (tz_net_load_prepare); the move after that the weights are swapped in (tz_net_load_commit)
+    bool async = false;
+    std::future<tz_pending_weights*> preparing;
 };
 
 // rank 0 (or the only process) looks at the file; with a communicator every rank then takes the same branch
@@ -37,6 +42,31 @@ static int reload_model(void* user) {
         const bool changed = stat(r->path.c_str(), &st) == 0 &&   // no model yet: keep playing with the current one
                              !(st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size &&
                                (long long)st.st_ino == r->inode);
+        if (r->async && !r->comm) {
+            if (r->preparing.valid() && r->preparing.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
+                if (tz_pending_weights* p = r->preparing.get()) {
+                    if (tz_net_load_commit(r->net, p) == 0) r->reloads++;
+                    else fprintf(stderr, "Cannot put the model in place: %s\n", tz_last_error());
+                }
+            }
+            if (changed && !r->preparing.valid()) {
+                tz_net* net = r->net;
+                const std::string path = r->path;
+                r->preparing = std::async(std::launch::async, [net, path]() -> tz_pending_weights* {
+                    tz_pending_weights* p = nullptr;
+                    if (tz_net_load_prepare(net, path.c_str(), &p) != 0) {
+                        fprintf(stderr, "Cannot load model: %s, not retrying.\n", tz_last_error());   // the old weights stay active
+                        return nullptr;
+                    }
+                    return p;
+                });
+                r->stamp_s = st.st_mtim.tv_sec;
+                r->stamp_ns = st.st_mtim.tv_nsec;
+                r->size = st.st_size;
+                r->inode = (long long)st.st_ino;
+            }
+            return 0;
+        }
         if (changed) {
             if (tz_net_load_weights(r->net, r->path.c_str()) != 0) {
                 fprintf(stderr, "Cannot load model: %s, not retrying.\n", tz_last_error());  // the old weights stay active
@@ -71,6 +101,7 @@ static int reload_model(void* user) {
 int main(int argc, char** argv) {
     std::string directory, model, search = "gumbel", watch = "model_latest.ot", comm_kind, comm_dir;
     int arch = TZ_ARCH_NET5, n = 5, blocks = 0, games = 128, sims = 768, moves = -1, exploration = 0, k = 64, precision = TZ_PREC_F16;
+    bool async_reload = false;
     int rank = 0, world = 1, device = -1;
     unsigned long long seed = 0;
     double wait_limit = -1.0;
@@ -89,6 +120,7 @@ int main(int argc, char** argv) {
         else if (a == "--sampled-actions") k = atoi(next());
         else if (a == "--wait-limit") wait_limit = atof(next());
         else if (a == "--watch") watch = next();
+        else if (a == "--async-reload") async_reload = true;
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
         else if (a == "--rank") rank = atoi(next());
         else if (a == "--world") world = atoi(next());
@@ -107,7 +139,7 @@ int main(int argc, char** argv) {
     }
     if (directory.empty() || (world > 1 && comm_kind != "rccl" && comm_kind != "fs")) {
         fprintf(stderr, "usage: selfplay_cli --directory DIR [--model FILE.ot|.tzw --watch model_latest.ot --arch 4|5|6|100 --n N --blocks K "
-                        "--games B --sims S --search puct|gumbel --sampled-actions K --moves M --exploration --f16|--bf16|--f16x2 "
+                        "--games B --sims S --search puct|gumbel --sampled-actions K --moves M --exploration --async-reload --f16|--bf16|--f16c8|--f16x2 "
                         "--wait-limit SECONDS --seed X] [--rank R --world N --comm rccl|fs --comm-dir D --device G]\n");
         return 2;
     }
@@ -136,6 +168,7 @@ int main(int argc, char** argv) {
         CHECK(tz_selfplay_set_comm(sp, comm, 0));
     }
     Reload reload{net, directory + "/" + watch, comm, rank};
+    reload.async = async_reload && !comm;
     const auto t0 = std::chrono::steady_clock::now();
     CHECK(tz_selfplay_run(sp, directory.c_str(), moves, 32000, "", reload_model, &reload, wait_limit));
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -152,6 +185,8 @@ int main(int argc, char** argv) {
     }
     printf("moves %llu targets %llu replays %llu simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f rss_mb %ld skipped_expansions %llu\n",
            played, targets, replays, simulations, evals, reload.reloads, seconds, (double)simulations / seconds, rss_kb / 1024, skipped);
+    if (reload.preparing.valid())
+        if (tz_pending_weights* p = reload.preparing.get()) tz_net_load_discard(p);
     tz_selfplay_destroy(sp);
     tz_search_destroy(mcts);
     tz_net_destroy(net);

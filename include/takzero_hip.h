@@ -140,6 +140,16 @@ int tz_net_init_random(tz_net* net, uint64_t seed);
  * the flat .tzw container of takzero_amd.weights (named fp32 tensors).  SimHash nets also pick up `bitvec.bin` from the
  * same directory when it is there.  A failed load leaves the previous weights active (selfplay/src/main.rs:112-115). */
 int tz_net_load_weights(tz_net* net, const char* path);
+/* The same load in two halves, for a host that does not want to stop playing while a new model_latest.ot is read (selfplay's
+ * hot reload, selfplay/src/main.rs:107-120).  tz_net_load_prepare parses the file and builds the device weights in fresh buffers;
+ * it touches nothing of the live network and may run on another thread while `net` is evaluating.  tz_net_load_commit puts them
+ * in place (a device synchronisation and a pointer swap; for a SimHash net also the bitvec.bin beside the file) and must be
+ * called where tz_net_load_weights could be: not concurrently with a forward of `net`.  A failed prepare leaves nothing behind;
+ * prepared weights that are not wanted any more go to tz_net_load_discard. */
+typedef struct tz_pending_weights tz_pending_weights;
+int tz_net_load_prepare(tz_net* net, const char* path, tz_pending_weights** out);
+int tz_net_load_commit(tz_net* net, tz_pending_weights* pending);
+int tz_net_load_discard(tz_pending_weights* pending);
 int tz_net_load_weights_mem(tz_net* net, const void* data, size_t bytes);
 /* Network::load_partial (network/mod.rs:30-35): variables the file does not hold (or holds with another size) keep their
  * values; their names come back newline-separated in missing_out (may be NULL), their number in n_missing_out. */

@@ -29,7 +29,7 @@ SYMBOLS = [
     "tz_search_new_openings", "tz_search_simulate", "tz_search_apply_noise", "tz_search_root_info",
     "tz_search_root_children", "tz_search_node", "tz_search_select_best_actions", "tz_search_improved_policy", "tz_search_ube_target",
     "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync", "tz_search_pool_usage",
-    "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_debug_net_clock", "tz_debug_net_stamps", "tz_search_terminal_details", "tz_search_play_moves",
+    "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_net_load_prepare", "tz_net_load_commit", "tz_net_load_discard", "tz_debug_net_clock", "tz_debug_net_stamps", "tz_search_terminal_details", "tz_search_play_moves",
     "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
     "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
     "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
@@ -138,6 +138,9 @@ def load():
     lib.tz_debug_tower_bench.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tz_debug_net_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.tz_debug_net_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]
+    lib.tz_net_load_prepare.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.tz_net_load_commit.argtypes = [vp, vp]
+    lib.tz_net_load_discard.argtypes = [vp]
     lib.tz_format_targets.argtypes = [ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.tz_parse_targets.argtypes = [vp, C.c_uint64, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32),
                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]

@@ -153,6 +153,18 @@ class Net:
         archive as tch writes it (+ `bitvec.bin` beside it for SimHash nets)."""
         check(self.lib.tz_net_save(self.h, str(path).encode()))
 
+    def load_prepare(self, path):
+        """First half of a load (tz_net_load_prepare): parse `path` and build its device weights in fresh buffers; the live
+        network is not touched, so this may run on another thread while the net is evaluating.  Returns a handle for load_commit."""
+        h = C.c_void_p()
+        check(self.lib.tz_net_load_prepare(self.h, os.fsencode(str(path)), C.byref(h)))
+        return h
+
+    def load_commit(self, pending):
+        """Second half (tz_net_load_commit): swap the prepared weights in; not concurrently with a forward of this net."""
+        check(self.lib.tz_net_load_commit(self.h, pending))
+        return self
+
     def load_partial(self, path):
         """Network::load_partial (network/mod.rs:30-35): variables missing from the file keep their current values;
         returns their names (tch's VarStore::load_partial)."""

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -2597,11 +2598,41 @@ int get_tensor(const TensorMap& m, const std::string& name, size_t expect, std::
     return TZ_OK;
 }
 
+// Copies of a weight build.  A build may run on a thread of its own while the search thread is capturing or replaying graphs on
+// its (blocking) streams (tz_net_load_prepare): a copy on the legacy stream would make that stream depend on the capturing one -
+// an error that also breaks the capture - so a build's copies go through a non-blocking stream of the building thread
+// (UploadStream), waited for copy by copy (the sources are short-lived host vectors).
+thread_local hipStream_t g_upload_stream = nullptr;
+struct UploadStream {
+    hipStream_t prev = nullptr, mine = nullptr;
+    UploadStream() {
+        prev = g_upload_stream;
+        if (hipStreamCreateWithFlags(&mine, hipStreamNonBlocking) == hipSuccess) g_upload_stream = mine;
+    }
+    ~UploadStream() {
+        g_upload_stream = prev;
+        if (mine) (void)hipStreamDestroy(mine);
+    }
+};
+int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (!g_upload_stream) {
+        TZ_HIP(hipMemcpy(dst, src, bytes, kind));
+        return TZ_OK;
+    }
+    TZ_HIP(hipMemcpyAsync(dst, src, bytes, kind, g_upload_stream));
+    TZ_HIP(hipStreamSynchronize(g_upload_stream));
+    return TZ_OK;
+}
+
 template <typename T>
 int upload(const std::vector<T>& h, T** dev) {
     T* d = nullptr;
     TZ_HIP(hipMalloc(&d, h.size() * sizeof(T)));
-    TZ_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    const int rc = copy_sync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (rc) {
+        (void)hipFree(d);
+        return rc;
+    }
     *dev = d;
     return TZ_OK;
 }
@@ -2780,11 +2811,13 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
         std::atomic<int> next{0}, failed{TZ_OK};
         std::string first_error;
         std::mutex mu;
+        const bool background = g_upload_stream != nullptr;   // a build beside a running search: every thread copies on a stream of its own
         auto work = [&]() {
             if (hipSetDevice(net->device) != hipSuccess) {
                 failed = TZ_EDEVICE;
                 return;
             }
+            std::unique_ptr<UploadStream> upload_stream(background ? new UploadStream() : nullptr);
             std::vector<float> lw, lscale, lbias;
             for (int l = next++; l < nl && failed == TZ_OK; l = next++) {
                 const std::string p = "core.res_block_" + std::to_string(l / 2) + ((l & 1) ? ".b" : ".a");
@@ -2814,10 +2847,10 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
         if (c8) TZ_HIP(hipMalloc(&W.tower_w8, nl * layer_bytes8));
         TZ_HIP(hipMalloc(&W.tower_bias, nl * FILTERS * sizeof(float)));
         for (size_t l = 0; l < nl; l++) {
-            TZ_HIP(hipMemcpy(W.tower_w + l * layer_elems, W.res[l].w_mfma, layer_elems * 2, hipMemcpyDeviceToDevice));
-            if (split) TZ_HIP(hipMemcpy(W.tower_w_lo + l * layer_elems, W.res[l].w_lo, layer_elems * 2, hipMemcpyDeviceToDevice));
-            if (c8) TZ_HIP(hipMemcpy(W.tower_w8 + l * layer_bytes8, W.res[l].w8, layer_bytes8, hipMemcpyDeviceToDevice));
-            TZ_HIP(hipMemcpy(W.tower_bias + l * FILTERS, W.res[l].bias, FILTERS * sizeof(float), hipMemcpyDeviceToDevice));
+            if ((rc = copy_sync(W.tower_w + l * layer_elems, W.res[l].w_mfma, layer_elems * 2, hipMemcpyDeviceToDevice))) return rc;
+            if (split && (rc = copy_sync(W.tower_w_lo + l * layer_elems, W.res[l].w_lo, layer_elems * 2, hipMemcpyDeviceToDevice))) return rc;
+            if (c8 && (rc = copy_sync(W.tower_w8 + l * layer_bytes8, W.res[l].w8, layer_bytes8, hipMemcpyDeviceToDevice))) return rc;
+            if ((rc = copy_sync(W.tower_bias + l * FILTERS, W.res[l].bias, FILTERS * sizeof(float), hipMemcpyDeviceToDevice))) return rc;
         }
     }
     if ((rc = get_tensor(m, "policy.conv2d.weight", (size_t)net->pol_ch * FILTERS * 9, w))) return rc;
@@ -2881,8 +2914,8 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
                 TZ_HIP(hipMalloc(&W.rndw[l], 2 * welems * 2));
                 TZ_HIP(hipMalloc(&W.rndb[l], 2 * belems * sizeof(float)));
                 for (int a = 0; a < 2; a++) {
-                    TZ_HIP(hipMemcpy(W.rndw[l] + a * welems, W.rnd[a][l].w_mfma, welems * 2, hipMemcpyDeviceToDevice));
-                    TZ_HIP(hipMemcpy(W.rndb[l] + a * belems, W.rnd[a][l].bias, belems * sizeof(float), hipMemcpyDeviceToDevice));
+                    if ((rc = copy_sync(W.rndw[l] + a * welems, W.rnd[a][l].w_mfma, welems * 2, hipMemcpyDeviceToDevice))) return rc;
+                    if ((rc = copy_sync(W.rndb[l] + a * belems, W.rnd[a][l].bias, belems * sizeof(float), hipMemcpyDeviceToDevice))) return rc;
                 }
             }
         }
@@ -3582,16 +3615,37 @@ int tz_net_create(int board_n, int arch, int device_id, int precision, int block
 
 // Replaces the network's weights by `store` (all or nothing: a failure leaves the previous weights active,
 // selfplay/src/main.rs:112-115) and keeps the store as the host copy of the VarStore (save / clone / load_partial).
-static int net_apply_store(tz_net* net, TensorStore&& store) {
-    TZ_HIP(hipSetDevice(net->device));
-    const TensorMap m = view_of(store);
+// A load in two halves.  Preparing (BatchNorm folding, fragment order, conversions, uploads into fresh buffers) reads only what
+// tz_net_create fixed, so it may run on any thread while the network is evaluating; committing waits for the device and swaps the
+// pointers, and must not run beside a forward of this network.
+struct tz_pending_weights {
+    TensorStore store;
     NetWeights W;
-    int rc = build_weights(net, m, W);
+    std::string path;
+    tz_net* net = nullptr;
+};
+
+static int net_prepare_store(tz_net* net, TensorStore&& store, tz_pending_weights** out, bool background) {
+    TZ_HIP(hipSetDevice(net->device));
+    tz_pending_weights* p = new tz_pending_weights();
+    p->store = std::move(store);
+    p->net = net;
+    const TensorMap m = view_of(p->store);
+    std::unique_ptr<UploadStream> upload_stream(background ? new UploadStream() : nullptr);
+    const int rc = build_weights(net, m, p->W);
     if (rc) {
-        free_weights(W);
+        free_weights(p->W);
+        delete p;
         return rc;
     }
-    TZ_HIP(hipDeviceSynchronize());  // searches run this net on their own streams; reloads are rare
+    *out = p;
+    return TZ_OK;
+}
+
+static int net_commit_pending(tz_net* net, tz_pending_weights* p) {
+    NetWeights& W = p->W;
+    TZ_HIP(hipSetDevice(net->device));
+    TZ_HIP(hipDeviceSynchronize());  // searches run this net on their own streams; the uploads above have landed too
     NetWeights old;
     old.conv_in = net->conv_in;
     old.policy = net->policy;
@@ -3626,10 +3680,17 @@ static int net_apply_store(tz_net* net, TensorStore&& store) {
     net->rnd_max = W.rnd_max;
     net->simhash = W.simhash;
     free_weights(old);
-    net->store = std::move(store);
+    net->store = std::move(p->store);
     net->loaded = true;
     net->weights_gen++;
+    delete p;
     return TZ_OK;
+}
+
+static int net_apply_store(tz_net* net, TensorStore&& store) {
+    tz_pending_weights* p = nullptr;
+    const int rc = net_prepare_store(net, std::move(store), &p, false);
+    return rc ? rc : net_commit_pending(net, p);
 }
 
 static bool file_exists(const std::string& p) {
@@ -3669,6 +3730,38 @@ int tz_net_load_weights(tz_net* net, const char* path) {
         const std::string bits = sibling(path, "bitvec.bin");
         if (file_exists(bits)) return tz_net_load_bitset(net, bits.c_str());
     }
+    return TZ_OK;
+}
+
+int tz_net_load_prepare(tz_net* net, const char* path, tz_pending_weights** out) {
+    if (!net || !path || !out) return tz_fail(TZ_EINVAL, "tz_net_load_prepare: null argument");
+    TensorStore store;
+    int rc = weights_read_file(path, store);
+    if (rc) return rc;
+    tz_pending_weights* p = nullptr;
+    if ((rc = net_prepare_store(net, std::move(store), &p, true))) return rc;
+    p->path = path;
+    *out = p;
+    return TZ_OK;
+}
+
+int tz_net_load_commit(tz_net* net, tz_pending_weights* p) {
+    if (!net || !p || p->net != net) return tz_fail(TZ_EINVAL, "tz_net_load_commit: these weights were not prepared for this network");
+    const std::string path = p->path;
+    int rc = net_commit_pending(net, p);
+    if (rc) return rc;
+    if (net->has_hash) {   // SimHash nets keep their set beside the model (net6_simhash.rs:173-190)
+        const std::string bits = sibling(path.c_str(), "bitvec.bin");
+        if (file_exists(bits)) return tz_net_load_bitset(net, bits.c_str());
+    }
+    return TZ_OK;
+}
+
+int tz_net_load_discard(tz_pending_weights* p) {
+    if (!p) return TZ_OK;
+    if (p->net) (void)hipSetDevice(p->net->device);
+    free_weights(p->W);
+    delete p;
     return TZ_OK;
 }
 

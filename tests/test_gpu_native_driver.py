@@ -181,10 +181,12 @@ def _fields(stdout):
     return dict(zip(stdout.split()[::2], stdout.split()[1::2]))
 
 
-def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
+@pytest.mark.parametrize("reload_flags", [[], ["--async-reload"]], ids=["sync", "async"])
+def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path, reload_flags):
     """examples/selfplay_cli.cpp: the selfplay binary as a plain C++ program linked against libtakzero_hip.so — no
     Python, no torch in the process.  It must produce the same kind of files, and pick up a new model_latest.ot (the
-    LibTorch archive the reference's learn writes: read by the library itself)."""
+    LibTorch archive the reference's learn writes: read by the library itself) — at once, or with --async-reload prepared on
+    another thread while the games go on and swapped in one move later (tz_net_load_prepare / tz_net_load_commit)."""
     import subprocess
 
     A = require_gpu()
@@ -198,7 +200,7 @@ def test_cpp_program_over_the_c_abi_alone(oracle, tmp_path):
     ot.save_ot(os.path.join(d, "model_latest.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
     open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
     r = subprocess.run([exe, "--directory", d, "--model", os.path.join(d, "start.tzw"), "--arch", "100", "--n", str(n), "--blocks", "1",
-                        "--games", "48", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel", "--moves", "60", "--wait-limit", "5"],
+                        "--games", "48", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel", "--moves", "60", "--wait-limit", "5"] + reload_flags,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
     fields = _fields(r.stdout)

@@ -355,6 +355,39 @@ def test_network_lifecycle_new_save_load_partial_clone(oracle, tmp_path):
     assert all(np.array_equal(x, y) for x, y in zip(c.forward_raw(states), want))
 
 
+def test_load_in_two_halves_while_the_net_is_evaluating(oracle, tmp_path):
+    """tz_net_load_prepare on another thread while the network keeps evaluating (the self-play process does not stop for a new
+    model_latest.ot), tz_net_load_commit between two forwards: outputs before the commit are the old model's, after it the new
+    model's, bit for bit what a plain load gives; a prepare of a torn file fails and leaves nothing behind."""
+    import threading
+
+    A = require_gpu()
+    n, blocks = 5, 3
+    old = A.Net.new(arch=A.ARCH_TEST, seed=5, n=n, blocks=blocks)
+    new = A.Net.new(arch=A.ARCH_TEST, seed=6, n=n, blocks=blocks)
+    new.save(tmp_path / "model_latest.ot")
+    states = O.states_array(random_positions(oracle, O, n, 4, 64, 3))
+    want_old, want_new = old.forward_raw(states), new.forward_raw(states)
+    box = {}
+
+    def prepare():
+        box["pending"] = old.load_prepare(tmp_path / "model_latest.ot")
+
+    th = threading.Thread(target=prepare)
+    th.start()
+    during = [old.forward_raw(states) for _ in range(20)]          # evaluating while the other thread parses, converts and uploads
+    th.join()
+    for out in during + [old.forward_raw(states)]:
+        assert all(np.array_equal(x, y) for x, y in zip(out, want_old))
+    old.load_commit(box["pending"])
+    assert all(np.array_equal(x, y) for x, y in zip(old.forward_raw(states), want_new))
+    blob = open(tmp_path / "model_latest.ot", "rb").read()
+    open(tmp_path / "torn.ot", "wb").write(blob[:len(blob) // 2])
+    with pytest.raises(A.TakzeroError):
+        old.load_prepare(tmp_path / "torn.ot")
+    assert all(np.array_equal(x, y) for x, y in zip(old.forward_raw(states), want_new))
+
+
 def test_simhash_net_saves_and_loads_its_set_beside_the_model(oracle, tmp_path):
     """net6_simhash.rs:152-190: Network::save writes bitvec.bin beside the .ot, Network::load reads it back; clone copies it."""
     A = require_gpu()
