@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <string>
 
 #include "takzero_hip.h"
@@ -21,6 +22,10 @@ struct Reload {
     std::string path;
     long long stamp_s = -1, stamp_ns = -1, size = -1, inode = -1;
     int reloads = 0;
+    // --async-reload: a changed file is parsed and its device weights are built on another thread while the iteration runs
+    // (tz_net_load_prepare); they are swapped in before the next one (tz_net_load_commit)
+    bool async = false;
+    std::future<tz_pending_weights*> preparing;
 };
 
 // reanalyze retries every kind of load failure (reanalyze/src/main.rs:93-105): a missing or torn file leaves the old net playing
@@ -29,7 +34,33 @@ static int reload_model(void* user) {
     Reload* r = static_cast<Reload*>(user);
     struct stat st;
     if (stat(r->path.c_str(), &st) != 0) return 0;
-    if (st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size && (long long)st.st_ino == r->inode) return 0;
+    const bool changed = !(st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size && (long long)st.st_ino == r->inode);
+    if (r->async) {
+        if (r->preparing.valid() && r->preparing.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
+            if (tz_pending_weights* p = r->preparing.get()) {
+                if (tz_net_load_commit(r->net, p) == 0) r->reloads++;
+                else fprintf(stderr, "Cannot put the model in place: %s\n", tz_last_error());
+            }
+        }
+        if (changed && !r->preparing.valid()) {
+            tz_net* net = r->net;
+            const std::string path = r->path;
+            r->preparing = std::async(std::launch::async, [net, path]() -> tz_pending_weights* {
+                tz_pending_weights* p = nullptr;
+                if (tz_net_load_prepare(net, path.c_str(), &p) != 0) {
+                    fprintf(stderr, "Cannot load model: %s, retrying when the file changes.\n", tz_last_error());
+                    return nullptr;
+                }
+                return p;
+            });
+            r->stamp_s = st.st_mtim.tv_sec;
+            r->stamp_ns = st.st_mtim.tv_nsec;
+            r->size = st.st_size;
+            r->inode = (long long)st.st_ino;
+        }
+        return 0;
+    }
+    if (!changed) return 0;
     if (tz_net_load_weights(r->net, r->path.c_str()) != 0) {
         fprintf(stderr, "Cannot load model: %s, retrying.\n", tz_last_error());
         return 0;
@@ -56,12 +87,14 @@ int main(int argc, char** argv) {
     int rank = 0, world = 1, device = -1, min_positions = 0;
     unsigned long long seed = 0;
     double wait_limit = -1.0;
+    bool async_reload = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
         if (a == "--directory") directory = next();
         else if (a == "--model") model = next();
         else if (a == "--watch") watch = next();
+        else if (a == "--async-reload") async_reload = true;
         else if (a == "--search") search = next();
         else if (a == "--arch") arch = atoi(next());
         else if (a == "--n") n = atoi(next());
@@ -87,7 +120,7 @@ int main(int argc, char** argv) {
     if (directory.empty()) {
         fprintf(stderr, "usage: reanalyze_cli --directory DIR [--model FILE --watch model_latest.ot --arch 4|5|6|100 --n N --blocks K --games B "
                         "--sims S --search puct|gumbel --sampled-actions K --iterations I --min-positions P --wait-limit SECONDS --seed X "
-                        "--rank R --world N --device G --bf16|--f16c8|--f16x2]\n");
+                        "--rank R --world N --device G --async-reload --bf16|--f16c8|--f16x2]\n");
         return 2;
     }
     if (arch == TZ_ARCH_NET5) n = 5;
@@ -103,6 +136,7 @@ int main(int argc, char** argv) {
     CHECK(tz_search_create(net, TZ_AGENT_NET, games, n, 4, 0, &mcts));
     CHECK(tz_reanalyze_create(mcts, sims, seed, rank, world, search == "puct" ? 0 : 1, k, &ra));
     Reload reload{net, directory + "/" + watch};
+    reload.async = async_reload;
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = tz_reanalyze_run(ra, directory.c_str(), iterations, min_positions, "", reload_model, &reload, wait_limit);
     if (rc != 0) fprintf(stderr, "tz_reanalyze_run stopped: %s\n", tz_last_error());
@@ -111,6 +145,8 @@ int main(int argc, char** argv) {
     CHECK(tz_search_counters(mcts, (uint64_t*)&simulations, (uint64_t*)&evals));
     printf("rc %d simulations %llu nn_evals %llu model_reloads %d seconds %.3f sims_per_s %.0f\n", rc, simulations, evals, reload.reloads, seconds,
            (double)simulations / seconds);
+    if (reload.preparing.valid())
+        if (tz_pending_weights* p = reload.preparing.get()) tz_net_load_discard(p);
     tz_reanalyze_destroy(ra);
     tz_search_destroy(mcts);
     tz_net_destroy(net);

@@ -237,7 +237,7 @@ def test_closed_loop_of_the_three_cpp_programs_over_ot_files(oracle, tmp_path):
         time.sleep(0.1)
     assert os.path.exists(os.path.join(d, "buffer_lengths.txt")), lp.communicate()[1][-1500:]
     rp = subprocess.Popen([reanalyze, "--directory", d, "--games", "64", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel",
-                           "--iterations", "12", "--min-positions", "500", "--wait-limit", "120", "--seed", "4"] + common,
+                           "--iterations", "12", "--min-positions", "500", "--wait-limit", "120", "--seed", "4", "--async-reload"] + common,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     sp = subprocess.run([selfplay, "--directory", d, "--games", "64", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel",
                          "--moves", "150", "--wait-limit", "60", "--seed", "9"] + common, capture_output=True, text=True, timeout=600)
