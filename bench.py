@@ -106,31 +106,104 @@ def cpu_baseline(seconds=12.0):
                        % (steps, dt))
 
 
+# TZ_PREC_F16C6 (csrc/tz_nn_c6.hip): per (tap, row tile, 16 outputs) of a tower conv 8 fp16 MFMAs (16x16x32) and 4 FP6-scaled
+# MFMAs (16x16x128), on 8 boards per workgroup (13 row tiles, 91 of 117 pairs); first conv in the split form (3 fp16 products)
+C6_ISSUED_F16 = 2 * 16 * 16 * 32 * 8 * 16 * (TOWER_LAYERS * TOWER_TILE_TAPS[0] + TOWER_TILE_TAPS[0] * 0.5) / 8.0 + 3 * 2 * 16 * 256 * 32 * 9 * 13 / 8.0
+C6_ISSUED_FP6 = 2 * 16 * 16 * 128 * 4 * 16 * (TOWER_LAYERS * TOWER_TILE_TAPS[0] + TOWER_TILE_TAPS[0] * 0.5) / 8.0
+PEAK_FP6_TFLOPS = 10000.0             # dense FP6 / FP4 MFMA peak (MI355X_MICROARCH.md, Matrix cores)
+
+
+def roofline_of(precision, prof, sims, evals, games):
+    """The `roofline` object of a measured run: algorithmic FLOPs per launch of the fused net kernel (1 197.5 MFLOP x the positions a
+    launch evaluated, from the device counters) over its average duration by HIP events on the engine's stream (mcts.profile)."""
+    per_launch_positions = evals / max(1.0, sims / games)
+    avg_ms = prof["conv_ms"] / prof["conv_launches"]
+    achieved = FLOP_PER_LAUNCH_POS * per_launch_positions / (avg_ms * 1e-3) / 1e12
+    split = precision in ("f16x2", "f16c8")
+    kernel_name, rows, issued, mix_peak = KERNEL_NAME, "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS, ISSUED_FLOP_PER_LAUNCH_POS, PEAK_BF16_TFLOPS
+    if split and FUSED_MODE == 2:
+        # 4 boards per workgroup (7 row tiles, 49 of 63 pairs issued) and three products per MAC: hi*hi on fp16 MFMAs, the two
+        # corrections on fp16 MFMAs (f16x2) or on FP8 MFMAs of 4x the K at twice the rate (f16c8) - the same issued FLOP count
+        kernel_name = ("net_mfma_kernel<5,4,1,SP=%d> (%s; same fusion)" %
+                       ((1, "hi/lo fp16 operands, 3 fp16 MFMAs per product") if precision == "f16x2"
+                        else (2, "fp16 product + 2 correction products on FP8 E4M3 copies, v_mfma_f32_16x16x128_f8f6f4")))
+        rows = "square-major, 49 of 63 (tap, row tile) pairs per tower conv issued"
+        issued = 3 * (2 * 16 * 256 * 32 * (9 * 7 * 1 + TOWER_LAYERS * 49 * 8 + 49 * 8 * 0.5)) / 4.0
+        # fp16 MFMAs at 2.5 PFLOP/s; f16c8 issues a third of its FLOPs there and two thirds on FP8 MFMAs at 5 PFLOP/s
+        mix_peak = 3750.0 if precision == "f16c8" else PEAK_BF16_TFLOPS
+    elif precision == "f16c6" and FUSED_MODE == 2:
+        kernel_name = ("net_c6_kernel<5,8,1> (fp16 product + 2 correction products on FP6 E2M3 block-scaled copies, "
+                       "v_mfma_scale_f32_16x16x128_f8f6f4; same fusion, 8 boards per workgroup)")
+        issued = C6_ISSUED_F16 + C6_ISSUED_FP6
+        mix_peak = issued / (C6_ISSUED_F16 / PEAK_BF16_TFLOPS + C6_ISSUED_FP6 / PEAK_FP6_TFLOPS)
+    traffic = None   # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/)
+    tpath = os.path.join(ROOT, "profiles", "tower_pmc_traffic.json")
+    if FUSED_MODE == 2 and games == GAMES and os.path.exists(tpath):
+        stored = json.load(open(tpath))
+        traffic = (stored.get(precision) or {}).get("hbm_bytes_per_launch") if precision != "f16" else stored.get("hbm_bytes_per_launch")
+    issued_tf = issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 if FUSED_MODE == 2 else None
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "traffic_source": ("stored figure, not measured in this run: profiles/tower_pmc_traffic.json (rocprofv3 --pmc "
+                               "passes of the same command; 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction)"
+                               if traffic is not None else None),
+            "kernel": kernel_name,
+            "rows": rows if FUSED_MODE == 2 else "board-major",
+            "issued_tflops": issued_tf,
+            # the MFMA mix's own ceiling: every issued FLOP priced at the dense peak of the instruction that issues it
+            "issued_frac_of_mfma_mix_peak": (issued_tf / mix_peak if FUSED_MODE == 2 else None),
+            # the chip's own best case beside the sheet figure: a bare loop of independent fp16 MFMAs with every operand in
+            # registers reaches 1.99 PFLOP/s (power-limited clock; tools/mfma_f8_probe.hip, profiles/r02_mfma_f8_probe.txt)
+            "bare_mfma_loop_tflops": {"value": 1986.0, "source": "stored figure: profiles/r02_mfma_f8_probe.txt (tools/mfma_f8_probe.hip, mode 0)"},
+            "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
+            "positions_per_launch": per_launch_positions}
+
+
+TOLERANCE_PRECISION = "f16c6"   # the cheapest arithmetic that holds the north star's 1e-3 on trained nets: timed at length, with its own roofline
+
+
 def precision_report(A, SP, W, args, primary_sims_per_s, moves=2):
-    """Throughput of the precisions the main measurement did not run (same workload, `moves` timed moves after one warm-up
-    move each) and the measured output errors of all of them against the library's fp32 path at random-init and at trained
-    logit scale (takzero_amd/precision.py).  The north star's tolerance (logits within 1e-3 of the fp32 path) is met by f16c8
-    (fp16 products + FP8 correction products) and f16x2 (hi / lo fp16 operands) at any scale, by f16 only while |logit| <~ 1."""
+    """Throughput of the precisions the main measurement did not run (same workload) and the measured output errors of all of them
+    against the library's fp32 path at random-init and at trained logit scale (takzero_amd/precision.py).  The north star's
+    tolerance (logits within 1e-3 of the fp32 path) is met by f16c6 / f16c8 (fp16 products + FP6 / FP8 correction products) and f16x2
+    (hi / lo fp16 operands) at any scale, by f16 only while |logit| <~ 1.  The cheapest of those (f16c6) is timed over 10 moves after
+    2 warm-up moves and gets a `roofline` object of its own (HIP events around every 8th launch of its net kernel, as for the
+    headline); the others over `moves` moves after one."""
     from takzero_amd import precision as P
 
-    names = ("f16", "f16c8", "f16x2")
+    names = ("f16", "f16c6", "f16c8", "f16x2")
     rates = {args.precision: primary_sims_per_s}
+    extra = {}
     for other in names:
         if other in rates:
             continue
+        long_run = other == TOLERANCE_PRECISION
         net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_NAMES[other])
         net.load_tensors(W.init_weights(W.ARCH_NET5, seed=123))
         mcts = A.BatchedMCTS(args.games, N_BOARD, HALF_KOMI, agent=net, node_capacity=args.capacity)
         sp = SP.NativeSelfPlay(mcts, args.sims, seed=0, shard=0, search=args.search, sampled_actions=64)
-        sp.play_move()
+        for _ in range(2 if long_run else 1):
+            sp.play_move()
         mcts.sync()
-        s0 = mcts.counters()[0]
+        mcts.profile(reset=1 if long_run else 2)
+        s0, e0 = mcts.counters()
         t0 = time.perf_counter()
-        for _ in range(moves):
+        n_moves = 10 if long_run else moves
+        for _ in range(n_moves):
             sp.play_move()
         mcts.sync()
         dt = time.perf_counter() - t0
-        rates[other] = (mcts.counters()[0] - s0) / dt
+        s1, e1 = mcts.counters()
+        rates[other] = (s1 - s0) / dt
+        if long_run:
+            prof = mcts.profile(reset=2)
+            extra[other] = {"timed_moves": n_moves, "warmup_moves": 2, "ms_per_step": 1000.0 * dt / n_moves,
+                            "nn_leaf_evals_per_s": (e1 - e0) / dt}
+            if prof["conv_launches"]:
+                extra[other]["roofline"] = roofline_of(other, prof, s1 - s0, e1 - e0, args.games)
+                extra[other]["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
+                                                         "dominant_kernel": prof["conv_ms"] / max(1, prof["steps"]),
+                                                         "wall": 1000.0 * dt / max(1.0, (s1 - s0) / args.games)}
         sp.close()
         mcts.close()
         net.close()
@@ -139,12 +212,13 @@ def precision_report(A, SP, W, args, primary_sims_per_s, moves=2):
     e0 = P.errors_against_f32(A.ARCH_NET5, w0, states, precisions=names)
     e1 = P.errors_against_f32(A.ARCH_NET5, P.trained_scale_weights(A.ARCH_NET5, states, seed=123), states, precisions=names)
     out = {"reference": e0["reference"], "positions": e0["positions"], "tolerance": "north star: logits within 1e-3 (absolute) of the fp32 path",
-           "timed_moves_of_the_other_precisions": moves}
+           "timed_moves_of_the_other_precisions": moves, "timed_moves_of_" + TOLERANCE_PRECISION: 10}
     for p in names:
         out[p] = {"sims_per_s": rates[p],
                   "random_init_scale": dict(e0[p], logit_scale=e0["logit_scale"]),
                   "trained_scale": dict(e1[p], logit_scale=e1["logit_scale"]),
                   "meets_1e-3_at_trained_scale": bool(e1[p]["max_abs_logit_err"] < 1e-3 and e1[p]["max_abs_value_err"] < 1e-3)}
+        out[p].update(extra.get(p, {}))
     return out
 
 
@@ -164,9 +238,10 @@ def main():
     ap.add_argument("--driver", choices=["native", "python"], default="native",
                     help="native = the self-play outer loop in csrc/tz_host.cpp (tz_selfplay_*); python = its mirror in "
                          "takzero_amd/selfplay.py")
-    ap.add_argument("--precision", choices=["bf16", "f16", "f16c8", "f16x2"], default=os.environ.get("TZ_PRECISION", "f16"),
+    ap.add_argument("--precision", choices=["bf16", "f16", "f16c6", "f16c8", "f16x2"], default=os.environ.get("TZ_PRECISION", "f16"),
                     help="arithmetic of the MFMA path: f16 (default) = fp16 storage, fp32 accumulate, ~1e-3 relative logit error "
-                         "through the 41 convs; f16c8 = the fp16 product plus FP8 (E4M3) correction products (1.4e-4 absolute at "
+                         "through the 41 convs; f16c6 = the fp16 product plus FP6 (E2M3, block-scaled) correction products, 8 boards per "
+                         "workgroup (1.4e-4 absolute at trained logit scale); f16c8 = the fp16 product plus FP8 (E4M3) correction products (1.4e-4 absolute at "
                          "trained logit scale, ~2.3x the f16 kernel time); f16x2 = split precision (hi/lo fp16 operands, 3 MFMAs per "
                          "product: 2.4e-5, ~3x); bf16 = the f16 kernels 5 %% faster at 1e-3 .. 7e-3 (random-init scale)")
     ap.add_argument("--no-precision-report", action="store_true",
@@ -343,42 +418,7 @@ def main():
             "host_driver": "native (csrc/tz_host.cpp)" if args.driver == "native" else "python (takzero_amd/selfplay.py)",
         }
         if not args.no_profile and prof["conv_launches"]:
-            per_launch_positions = (evals1 - evals0) / max(1.0, (sims1 - sims0) / args.games)
-            flop_per_launch = FLOP_PER_LAUNCH_POS * per_launch_positions
-            avg_ms = prof["conv_ms"] / prof["conv_launches"]
-            achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-            traffic = None   # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/)
-            tpath = os.path.join(ROOT, "profiles", "tower_pmc_traffic.json")
-            split = args.precision in ("f16x2", "f16c8")
-            if FUSED_MODE == 2 and args.games == GAMES and os.path.exists(tpath):
-                stored = json.load(open(tpath))
-                traffic = (stored.get(args.precision) or {}).get("hbm_bytes_per_launch") if split else stored.get("hbm_bytes_per_launch")
-            kernel_name, rows, issued = KERNEL_NAME, "square-major, %d of %d (tap, row tile) pairs per tower conv issued" % TOWER_TILE_TAPS, ISSUED_FLOP_PER_LAUNCH_POS
-            if split and FUSED_MODE == 2:
-                # 4 boards per workgroup (7 row tiles, 49 of 63 pairs issued) and three products per MAC: hi*hi on fp16 MFMAs, the two
-                # corrections on fp16 MFMAs (f16x2) or on FP8 MFMAs of 4x the K at twice the rate (f16c8) - the same issued FLOP count
-                kernel_name = ("net_mfma_kernel<5,4,1,SP=%d> (%s; same fusion)" %
-                               ((1, "hi/lo fp16 operands, 3 fp16 MFMAs per product") if args.precision == "f16x2"
-                                else (2, "fp16 product + 2 correction products on FP8 E4M3 copies, v_mfma_f32_16x16x128_f8f6f4")))
-                rows = "square-major, 49 of 63 (tap, row tile) pairs per tower conv issued"
-                issued = 3 * (2 * 16 * 256 * 32 * (9 * 7 * 1 + TOWER_LAYERS * 49 * 8 + 49 * 8 * 0.5)) / 4.0
-            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                               "traffic_source": ("stored figure, not measured in this run: profiles/tower_pmc_traffic.json (rocprofv3 --pmc "
-                                                  "passes of the same command; 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction)"
-                                                  if traffic is not None else None),
-                               "kernel": kernel_name,
-                               "rows": rows if FUSED_MODE == 2 else "board-major",
-                               "issued_tflops": (issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 if FUSED_MODE == 2 else None),
-                               # the MFMA mix's own ceiling: fp16 MFMAs at 2.5 PFLOP/s; f16c8 issues a third of its FLOPs there and two
-                               # thirds on FP8 MFMAs at 5 PFLOP/s -> 3.75 PFLOP/s for the mix
-                               "issued_frac_of_mfma_mix_peak": (issued * per_launch_positions / (avg_ms * 1e-3) / 1e12 /
-                                                                (3750.0 if args.precision == "f16c8" else PEAK_BF16_TFLOPS) if FUSED_MODE == 2 else None),
-                               # the chip's own best case beside the sheet figure: a bare loop of independent fp16 MFMAs with every operand in
-                               # registers reaches 1.99 PFLOP/s (power-limited clock; tools/mfma_f8_probe.hip, profiles/r02_mfma_f8_probe.txt)
-                               "bare_mfma_loop_tflops": {"value": 1986.0, "source": "stored figure: profiles/r02_mfma_f8_probe.txt (tools/mfma_f8_probe.hip, mode 0)"},
-                               "avg_launch_ms": avg_ms, "launches": prof["conv_launches"],
-                               "positions_per_launch": per_launch_positions}
+            out["roofline"] = roofline_of(args.precision, prof, sims1 - sims0, evals1 - evals0, args.games)
             out["time_split_ms_per_sim"] = {"tree_kernels": prof["tree_ms"] / max(1, prof["steps"]),
                                             "dominant_kernel": prof["conv_ms"] / max(1, prof["steps"]),
                                             "wall": 1000.0 * dt / max(1.0, (sims1 - sims0) / args.games)}
@@ -388,7 +428,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the checker must not take the measurement down with it
                 out["cpu_baseline"] = {"error": repr(e)}
-        if world == 1 and not args.no_precision_report and args.games == GAMES and args.precision in ("f16", "f16c8", "f16x2"):
+        if world == 1 and not args.no_precision_report and args.games == GAMES and args.precision in ("f16", "f16c6", "f16c8", "f16x2"):
             # the other precision's throughput and both measured errors: close the first engine (66 GB of pools)
             sp.close()
             mcts.close()

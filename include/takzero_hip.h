@@ -109,6 +109,10 @@ typedef struct tz_search tz_search; /* opaque: BatchedMCTS<B, Game<N,HALF_KOMI>>
                           v_mfma_f32_16x16x128_f8f6f4 (twice the fp16 rate): a correction only has to be good to a few
                           bits.  Logits within 1e-3 absolute at trained logit scale like TZ_PREC_F16X2 (about 30x
                           closer to fp32 than TZ_PREC_F16), ~2x the MFMA time of TZ_PREC_F16 instead of 3x */
+#define TZ_PREC_F16C6 5 /* the same with the corrections on FP6 (E2M3) copies and one power-of-two scale per block of 32 input
+                          channels, through v_mfma_scale_f32_16x16x128_f8f6f4 at four times the fp16 rate (round 3): 1.5x the
+                          MFMA time of TZ_PREC_F16, 8 boards per workgroup like it, the same logit error as TZ_PREC_F16C8.
+                          5x5 and 6x6 networks. */
 
 /* built-in agents for tz_search_create (takzero/src/search/agent.rs:16-87) */
 #define TZ_AGENT_NET 0

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ROOT_INFO_DTYPE, STATE_DTYPE, TakzeroError, check
 
 ARCH_NET4_SIMHASH, ARCH_NET5, ARCH_NET6_SIMHASH, ARCH_TEST = 4, 5, 6, 100
-PREC_BF16, PREC_F32, PREC_F16, PREC_F16X2, PREC_F16C8 = 0, 1, 2, 3, 4
+PREC_BF16, PREC_F32, PREC_F16, PREC_F16X2, PREC_F16C8, PREC_F16C6 = 0, 1, 2, 3, 4, 5
 # Arithmetic of the trunk.  fp16 storage with fp32 accumulation (PREC_F16) is the throughput default: its logits are within
 # ~2e-4 *relative* of the fp32 graph through the 41 stacked convs (1.5e-4 absolute at the random-init logit scale of 0.2,
 # ~2e-3 at a trained net's logit scale of 10).  PREC_F16X2 ("f16x2") carries every operand as a hi / lo pair of halves
@@ -25,7 +25,7 @@ PREC_BF16, PREC_F32, PREC_F16, PREC_F16X2, PREC_F16C8 = 0, 1, 2, 3, 4
 # for a host that wants the reference's moves (under Gumbel 64 / 768 at trained scale the fp16 default picks the fp32 path's
 # action in 93 % of games, these two in all of them).  bf16 runs the fp16 kernels 5 % faster at 1e-3 .. 7e-3 (random-init
 # scale).  TZ_PRECISION selects.
-PREC_NAMES = {"bf16": PREC_BF16, "f16": PREC_F16, "f32": PREC_F32, "f16x2": PREC_F16X2, "f16c8": PREC_F16C8}
+PREC_NAMES = {"bf16": PREC_BF16, "f16": PREC_F16, "f32": PREC_F32, "f16x2": PREC_F16X2, "f16c8": PREC_F16C8, "f16c6": PREC_F16C6}
 PREC_DEFAULT = PREC_NAMES[os.environ.get("TZ_PRECISION", "f16")]
 AGENT_NET, AGENT_DUMMY, AGENT_SIMPLE = 0, 1, 2
 EVAL_VALUE, EVAL_WIN, EVAL_LOSS, EVAL_DRAW = 0, 1, 2, 3

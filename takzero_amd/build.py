@@ -19,6 +19,9 @@ UNITS = [
     ("tz_capi.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("tz_nn.hip", []),
     ("tz_nn_split.hip", []),          # includes tz_nn.hip with TZ_NN_SPLIT_TU: the split-precision kernels, compiled in parallel
+    ("tz_nn_c6.hip", []),             # the same for TZ_PREC_F16C6 (FP6 block-scaled corrections): its own kernel on tz_nn.hip's templates,
+    ("tz_nn_c6b.hip", []),            #   its workgroup forms spread over three units (5x5 full size / 5x5 small batches / 6x6)
+    ("tz_nn_c6c.hip", []),
     ("tz_learn.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function",
@@ -55,8 +58,8 @@ def build(force=False, verbose=False, ablations=None):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        nn = src in ("tz_nn.hip", "tz_nn_split.hip")
-        deps = [s] + headers + ([os.path.join(CSRC, "tz_nn.hip")] if nn else [])
+        nn = src in ("tz_nn.hip", "tz_nn_split.hip", "tz_nn_c6.hip", "tz_nn_c6b.hip", "tz_nn_c6c.hip")
+        deps = [s] + headers + ([os.path.join(CSRC, "tz_nn.hip")] if nn else []) + ([os.path.join(CSRC, "tz_nn_c6.hip")] if src.startswith("tz_nn_c6") else [])
         if force or _stale(o, deps) or (force_nn and nn):
             cmd = [hipcc] + COMMON + extra + (["-DTZ_ABLATIONS"] if ablations and nn else []) + ["-x", "hip", "-c", s, "-o", o]
             if verbose:

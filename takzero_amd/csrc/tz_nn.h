@@ -11,7 +11,7 @@ struct ConvW {
     int taps = 0, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
     uint16_t* w_mfma = nullptr;  // bf16 / fp16 bits, fragment order [tap][kc][ct][lane][8]
     uint16_t* w_lo = nullptr;    // TZ_PREC_F16X2: fp16((w - hi) * 2^11) in the same order
-    unsigned char* w8 = nullptr; // TZ_PREC_F16C8: FP8 E4M3 fragments [tap][m = cin/128][ct][term: lo, hi][lane][32] of (w - hi) * 2^11 * s and hi * s
+    unsigned char* w8 = nullptr; // TZ_PREC_F16C6: E2M3 records (build_layer); TZ_PREC_F16C8: FP8 E4M3 fragments [tap][m = cin/128][ct][term: lo, hi][lane][32] of (w - hi) * 2^11 * s and hi * s
     float c8_scale = 0.0f;       //   what the correction accumulator is multiplied by: 2^-11 / (s * C8_SX), s = the layer's power of two
     float* w_f32 = nullptr;      // [tap][cout][cin]
     float* bias = nullptr;       // [cout_pad]  (BatchNorm folded in)
@@ -45,6 +45,7 @@ struct tz_net {
     float *value = nullptr, *ube = nullptr, *variance = nullptr, *aux = nullptr;  // [max_batch]
     void *rnd_in = nullptr, *rnd_h1 = nullptr, *rnd_h2 = nullptr;  // RND activations
     float* rnd_out = nullptr;                                       // [2][max_batch][512]
+    void* seeds = nullptr;     // TZ_PREC_F16C6: the blocks' inputs (fp32) between the two convs of a block (tz_nn_c6.hip)
     hipStream_t stream = nullptr;
     void* dbg_buf = nullptr;   // diagnostic builds: in-kernel stamps of the last launch (tz_debug_net_clock)
     int dbg_groups = 0;

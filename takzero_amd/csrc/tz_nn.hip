@@ -16,6 +16,7 @@
 //   * an fp32 validation path (TZ_PREC_F32) with plain FMA kernels for the 1e-3 logit gate.
 #include "tz_nn.h"
 #include "tz_fp8.h"
+#include "tz_fp6.h"
 #include <type_traits>
 #include "tz_ot.h"
 
@@ -31,6 +32,8 @@
 #include <thread>
 
 int tz_nn_launch_split(int sp, int n, const void* net_args, int max_positions, hipStream_t st);   // the second translation unit
+int tz_nn_launch_c6(int n, const void* net_args, int max_positions, hipStream_t st);                // the third (tz_nn_c6.hip)
+size_t tz_nn_c6_seed_bytes(int n, int max_positions);
 
 namespace {
 
@@ -96,6 +99,18 @@ struct LdsImg {
         return (ok ? v : zrow) * ROW_PAD + q * 16;
     }
 };
+
+// TZ_PREC_F16C6 (tz_nn_c6.hip): place of real channel 32 w + o in its image - plane 4 (w / 4) + o / 8, piece w % 4, element o % 8 -
+// and the channel at a place; the weights' input channels are permuted to match on the host (build_layer)
+__host__ __device__ constexpr int c6_position_of(int c) {
+    const int w = c >> 5, o = c & 31;
+    return 32 * (4 * (w >> 2) + (o >> 3)) + 8 * (w & 3) + (o & 7);
+}
+__host__ __device__ constexpr int c6_channel_at(int pos) {
+    const int plane = pos >> 5, piece = (pos >> 3) & 3, e = pos & 7;
+    return 32 * (4 * (plane >> 2) + piece) + 8 * (plane & 3) + e;
+}
+static_assert(c6_channel_at(c6_position_of(77)) == 77 && c6_position_of(c6_channel_at(200)) == 200 && c6_position_of(32) == 8 && c6_position_of(8) == 32, "c6 channel places");
 
 __host__ __device__ constexpr int ppt_for(int nb) { return nb == 1 ? 64 : nb == 3 ? 16 : nb == 4 ? 12 : nb == 5 ? 8 : 4; }
 
@@ -926,6 +941,8 @@ struct NetArgs {
     const unsigned char* w_pol8;
     const float* c8_scales;
     unsigned long long* dbg;   // diagnostic builds (ABL & 8): [workgroup][4] = memtime, memrealtime before / after the tower
+    // TZ_PREC_F16C6 (tz_nn_c6.hip): w8 / w_pol8 hold its E2M3 records; a block's input (fp32) waits here for the block's second conv
+    void* seeds;
 };
 
 // 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
@@ -2565,8 +2582,9 @@ uint16_t f2h(float f) {  // IEEE binary16, round to nearest even (host clang has
 // TZ_PREC_F16X2 runs the fp16 kernels everywhere (RND side networks included) except in the fused trunk + heads launch,
 // where every operand is a hi / lo pair of halves (k_loop_split)
 // TZ_PREC_F16C8 likewise; its fused launch takes the correction products through FP8 copies of the operands (k_loop_c8)
-inline bool prec_is_f16(int precision) { return precision == TZ_PREC_F16 || precision == TZ_PREC_F16X2 || precision == TZ_PREC_F16C8; }
-inline bool prec_is_split(int precision) { return precision == TZ_PREC_F16X2 || precision == TZ_PREC_F16C8; }
+// TZ_PREC_F16C6 likewise, with E2M3 block-scaled copies (tz_nn_c6.hip)
+inline bool prec_is_f16(int precision) { return precision == TZ_PREC_F16 || precision == TZ_PREC_F16X2 || precision == TZ_PREC_F16C8 || precision == TZ_PREC_F16C6; }
+inline bool prec_is_split(int precision) { return precision == TZ_PREC_F16X2 || precision == TZ_PREC_F16C8 || precision == TZ_PREC_F16C6; }
 
 struct Tensor {
     std::vector<uint32_t> dims;
@@ -2641,7 +2659,7 @@ int upload(const std::vector<T>& h, T** dev) {
 // in_perm (optional): source input index for each of my input indices.
 int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const std::vector<float>& w,
                 const std::vector<float>& scale, const std::vector<float>& bias, const std::vector<int>* in_perm,
-                ConvW* L, bool with_lo = false, bool with_c8 = false) {
+                ConvW* L, bool with_lo = false, bool with_c8 = false, bool with_c6 = false) {
     L->taps = taps;
     L->cin = cin;
     L->cin_pad = (cin + 31) / 32 * 32;
@@ -2712,6 +2730,51 @@ int build_layer(int precision, int taps, int cin, int cout, int cout_mult, const
                             }
                         }
             if ((rc = upload(p8, &L->w8))) return rc;
+        }
+        if (with_c6) {
+            // E2M3 records of the two correction products (k_loop_c6, tz_nn_c6.hip).  One record per (tap, K-half G of 128 input
+            // channels, output tile ct): [term: wl, wh][lane][16 B] + [lane][8 B] (the 24-B operand string of a lane, element i in
+            // bits 6 i ..), then [lane] one dword of scales (byte 0: wl's block, byte 1: wh's block; E8M0, 2^(byte - 127)).  Lane
+            // (row = lane & 15, q = lane >> 4) holds the block of 32 input places 128 G + 32 (i / 8) + 8 q + i % 8: the 8 elements of
+            // lane group q in each of the half's four fp16 fragments.  (in_perm has already moved the channels to their places.)
+            if (L->cin_pad % 128) return tz_fail(TZ_EINVAL, "weights: TZ_PREC_F16C6 needs input channels in multiples of 128");
+            const int g_total = L->cin_pad / 128;
+            constexpr size_t REC = 3328;
+            std::vector<unsigned char> p6((size_t)taps * g_total * ct_total * REC, 0);
+            for (int t = 0; t < taps; t++)
+                for (int g = 0; g < g_total; g++)
+                    for (int ct = 0; ct < ct_total; ct++) {
+                        unsigned char* rec = p6.data() + (((size_t)t * g_total + g) * ct_total + ct) * REC;
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int co = ct * 16 + (lane & 15), q = lane >> 4;
+                            float lo[32], hi[32], amax_l = 0.0f, amax_h = 0.0f;
+                            for (int i = 0; i < 32; i++) {
+                                const int ci = 128 * g + 32 * (i >> 3) + 8 * q + (i & 7);
+                                const float wv = (co < cout && ci < cin) ? W(co, ci, t) : 0.0f;
+                                const _Float16 h = (_Float16)wv;
+                                hi[i] = (float)h;
+                                lo[i] = wv - (float)h;
+                                amax_h = std::max(amax_h, fabsf(hi[i]));
+                                amax_l = std::max(amax_l, fabsf(lo[i]));
+                            }
+                            const uint32_t bl = tz_e2m3_block_scale_byte(amax_l), bh = tz_e2m3_block_scale_byte(amax_h);
+                            uint8_t cl[32], ch[32];
+                            for (int i = 0; i < 32; i++) {
+                                cl[i] = tz_f32_to_e2m3(ldexpf(lo[i], 127 - (int)bl));
+                                ch[i] = tz_f32_to_e2m3(ldexpf(hi[i], 127 - (int)bh));
+                            }
+                            uint32_t sl[6], sh[6];
+                            tz_pack_fp6x32(cl, sl);
+                            tz_pack_fp6x32(ch, sh);
+                            memcpy(rec + 0 * 1536 + lane * 16, sl, 16);
+                            memcpy(rec + 0 * 1536 + 1024 + lane * 8, sl + 4, 8);
+                            memcpy(rec + 1 * 1536 + lane * 16, sh, 16);
+                            memcpy(rec + 1 * 1536 + 1024 + lane * 8, sh + 4, 8);
+                            const uint32_t sw = bl | (bh << 8);
+                            memcpy(rec + 3072 + lane * 4, &sw, 4);
+                        }
+                    }
+            if ((rc = upload(p6, &L->w8))) return rc;
         }
         return upload(p, &L->w_mfma);
     }
@@ -2799,9 +2862,13 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
     int rc;
     if ((rc = get_tensor(m, "core.input_conv2d.weight", (size_t)FILTERS * cin * 9, w))) return rc;
     if ((rc = bn_fold(m, "core.batch_norm", FILTERS, scale, bias))) return rc;
-    const bool split = prec == TZ_PREC_F16X2, c8 = prec == TZ_PREC_F16C8;
-    // the first conv of TZ_PREC_F16C8 is the split form too: its input planes are built in the kernel, its k-loop is 9 steps
-    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in, split || c8))) return rc;
+    const bool split = prec == TZ_PREC_F16X2, c8 = prec == TZ_PREC_F16C8, c6 = prec == TZ_PREC_F16C6;
+    // TZ_PREC_F16C6: every conv that reads the tower's image takes its input channels from their places there (c6_channel_at)
+    std::vector<int> c6_perm(FILTERS);
+    for (int pos = 0; pos < FILTERS; pos++) c6_perm[pos] = c6_channel_at(pos);
+    const std::vector<int>* tower_perm = c6 ? &c6_perm : nullptr;
+    // the first conv of TZ_PREC_F16C8 / F16C6 is the split form too: its input planes are built in the kernel, its k-loop is 9 steps
+    if ((rc = build_layer(prec, 9, cin, FILTERS, 256, w, scale, bias, nullptr, &W.conv_in, split || c8 || c6))) return rc;
     W.res.resize(2 * net->blocks);
     {
         // the tower's layers are independent (BatchNorm folding, fragment order, fp16 / FP8 conversion, upload: 9 ms each on one host
@@ -2823,7 +2890,7 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
                 const std::string p = "core.res_block_" + std::to_string(l / 2) + ((l & 1) ? ".b" : ".a");
                 int r = get_tensor(m, p + ".conv2d.weight", (size_t)FILTERS * FILTERS * 9, lw);
                 if (!r) r = bn_fold(m, p + ".batch_norm", FILTERS, lscale, lbias);
-                if (!r) r = build_layer(prec, 9, FILTERS, FILTERS, 256, lw, lscale, lbias, nullptr, &W.res[l], split, c8);
+                if (!r) r = build_layer(prec, 9, FILTERS, FILTERS, 256, lw, lscale, lbias, tower_perm, &W.res[l], split, c8, c6);
                 if (r) {
                     std::lock_guard<std::mutex> lk(mu);
                     if (failed == TZ_OK) {
@@ -2843,19 +2910,19 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
         const size_t layer_elems = (size_t)9 * 8 * 16 * 64 * 8, nl = W.res.size();
         TZ_HIP(hipMalloc(&W.tower_w, nl * layer_elems * 2));
         if (split) TZ_HIP(hipMalloc(&W.tower_w_lo, nl * layer_elems * 2));
-        const size_t layer_bytes8 = (size_t)9 * 2 * 16 * 2 * 64 * 32;
-        if (c8) TZ_HIP(hipMalloc(&W.tower_w8, nl * layer_bytes8));
+        const size_t layer_bytes8 = c6 ? (size_t)9 * 2 * 16 * 3328 : (size_t)9 * 2 * 16 * 2 * 64 * 32;
+        if (c8 || c6) TZ_HIP(hipMalloc(&W.tower_w8, nl * layer_bytes8));
         TZ_HIP(hipMalloc(&W.tower_bias, nl * FILTERS * sizeof(float)));
         for (size_t l = 0; l < nl; l++) {
             if ((rc = copy_sync(W.tower_w + l * layer_elems, W.res[l].w_mfma, layer_elems * 2, hipMemcpyDeviceToDevice))) return rc;
             if (split && (rc = copy_sync(W.tower_w_lo + l * layer_elems, W.res[l].w_lo, layer_elems * 2, hipMemcpyDeviceToDevice))) return rc;
-            if (c8 && (rc = copy_sync(W.tower_w8 + l * layer_bytes8, W.res[l].w8, layer_bytes8, hipMemcpyDeviceToDevice))) return rc;
+            if ((c8 || c6) && (rc = copy_sync(W.tower_w8 + l * layer_bytes8, W.res[l].w8, layer_bytes8, hipMemcpyDeviceToDevice))) return rc;
             if ((rc = copy_sync(W.tower_bias + l * FILTERS, W.res[l].bias, FILTERS * sizeof(float), hipMemcpyDeviceToDevice))) return rc;
         }
     }
     if ((rc = get_tensor(m, "policy.conv2d.weight", (size_t)net->pol_ch * FILTERS * 9, w))) return rc;
     if ((rc = get_tensor(m, "policy.conv2d.bias", net->pol_ch, bias))) return rc;
-    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, nullptr, &W.policy, split, c8))) return rc;
+    if ((rc = build_layer(prec, 9, FILTERS, net->pol_ch, net->pol_stride, w, {}, bias, tower_perm, &W.policy, split, c8, c6))) return rc;
     if (c8) {
         std::vector<float> cs;
         for (auto& l : W.res) cs.push_back(l.c8_scale);
@@ -3167,7 +3234,9 @@ int net_small_p(int max_positions) {
     return max_positions <= 256 ? 1 : max_positions <= 512 ? 2 : max_positions <= 1024 ? 4 : 0;
 }
 
-#ifdef TZ_NN_SPLIT_TU
+#if defined(TZ_NN_C6_TU)
+}  // namespace   (tz_nn_c6.hip goes on from here)
+#elif defined(TZ_NN_SPLIT_TU)
 }  // namespace
 
 // The split-precision launches (TZ_PREC_F16X2: sp = 1, TZ_PREC_F16C8: sp = 2) live in their own translation unit so that the two
@@ -3301,6 +3370,7 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.w_pol8 = net->policy.w8;
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
+    a.seeds = net->seeds;
 #ifdef TZ_ABLATIONS
     if (getenv("TZ_NET_ABL") && (atoi(getenv("TZ_NET_ABL")) == 8 || (atoi(getenv("TZ_NET_ABL")) & 16))) {
         if (!net->dbg_buf) TZ_HIP(hipMalloc(&net->dbg_buf, (size_t)65536 * 4 * sizeof(unsigned long long)));
@@ -3308,6 +3378,7 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
         net->dbg_groups = (max_positions + (prec_is_split(net->precision) ? 3 : 7)) / (prec_is_split(net->precision) ? 4 : 8);
     }
 #endif
+    if (net->precision == TZ_PREC_F16C6) return tz_nn_launch_c6(net->n, &a, max_positions, st);   // tz_nn_c6.hip
     if (prec_is_split(net->precision)) return tz_nn_launch_split(net->precision == TZ_PREC_F16C8 ? 2 : 1, net->n, &a, max_positions, st);   // tz_nn_split.hip
     if (net->precision == TZ_PREC_F16) return net_fused_et<_Float16>(net, a, max_positions, st);
     return net_fused_et<__bf16>(net, a, max_positions, st);
@@ -3377,7 +3448,7 @@ int tz_net_ensure_batch(tz_net* net, int batch) {
     TZ_HIP(hipStreamSynchronize(net->stream));
     void** bufs[] = {&net->act_a, &net->act_b, &net->act_c, (void**)&net->planes, (void**)&net->policy_out,
                      (void**)&net->value, (void**)&net->ube, (void**)&net->variance, (void**)&net->aux,
-                     &net->rnd_in, &net->rnd_h1, &net->rnd_h2, (void**)&net->rnd_out};
+                     &net->rnd_in, &net->rnd_h1, &net->rnd_h2, (void**)&net->rnd_out, &net->seeds};
     for (auto b : bufs) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;
@@ -3393,6 +3464,7 @@ int tz_net_ensure_batch(tz_net* net, int batch) {
     TZ_HIP(hipMalloc(&net->ube, batch * sizeof(float)));
     TZ_HIP(hipMalloc(&net->variance, batch * sizeof(float)));
     TZ_HIP(hipMalloc(&net->aux, batch * sizeof(float)));
+    if (net->precision == TZ_PREC_F16C6) TZ_HIP(hipMalloc(&net->seeds, tz_nn_c6_seed_bytes(net->n, batch)));
     if (net->has_rnd) {
         const size_t in_pad = (size_t)(net->cin * net->nn + 31) / 32 * 32;
         TZ_HIP(hipMalloc(&net->rnd_in, (size_t)batch * in_pad * esz));
@@ -3416,7 +3488,7 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
     const bool split = prec_is_split(net->precision);
     if (split && !(net->blocks > 0 && (net->tower_w_lo || net->tower_w8)))
-        return tz_fail(TZ_EINVAL, "forward: TZ_PREC_F16X2 / TZ_PREC_F16C8 need a network with at least one residual block");
+        return tz_fail(TZ_EINVAL, "forward: TZ_PREC_F16X2 / TZ_PREC_F16C8 / TZ_PREC_F16C6 need a network with at least one residual block");
     if (bf && net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split)) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (net->profile) {
@@ -3578,8 +3650,10 @@ int tz_net_create(int board_n, int arch, int device_id, int precision, int block
     else if (arch != TZ_ARCH_TEST) return tz_fail(TZ_EINVAL, "tz_net_create: unknown architecture");
     if (board_n && board_n != n) return tz_fail(TZ_EINVAL, "tz_net_create: board size does not match the architecture");
     if (n < 3 || n > 6) return tz_fail(TZ_EINVAL, "tz_net_create: board size must be 3..6");
-    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16 && precision != TZ_PREC_F16X2 && precision != TZ_PREC_F16C8)
+    if (precision != TZ_PREC_BF16 && precision != TZ_PREC_F32 && precision != TZ_PREC_F16 && precision != TZ_PREC_F16X2 && precision != TZ_PREC_F16C8 &&
+        precision != TZ_PREC_F16C6)
         return tz_fail(TZ_EINVAL, "tz_net_create: bad precision");
+    if (precision == TZ_PREC_F16C6 && n != 5 && n != 6) return tz_fail(TZ_EINVAL, "tz_net_create: TZ_PREC_F16C6 is built for the 5x5 and 6x6 networks");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return tz_fail(TZ_EDEVICE, "tz_net_create: no HIP device available (the HIP path has no CPU fallback)");
@@ -4200,7 +4274,7 @@ int tz_net_destroy(tz_net* net) {
     old.simhash = net->simhash;
     free_weights(old);
     void* bufs[] = {net->act_a, net->act_b, net->act_c, net->planes, net->policy_out, net->value, net->ube,
-                    net->variance, net->aux, net->rnd_in, net->rnd_h1, net->rnd_h2, net->rnd_out, net->bitset};
+                    net->variance, net->aux, net->rnd_in, net->rnd_h1, net->rnd_h2, net->rnd_out, net->bitset, net->seeds};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& ev : net->conv_events) {

@@ -169,6 +169,58 @@ def test_f16c8_saturating_activations_stay_finite(oracle):
     assert float(np.abs(pol - outs[A.PREC_F32][0]).max()) < 2e-3 * scale
 
 
+C6_NETS = [(100, 5, 3, 19), (100, 6, 2, 9), (5, 5, 20, 10), (6, 6, 16, 6)]
+
+
+@pytest.mark.parametrize("arch,n,blocks,batch", C6_NETS)
+def test_f16c6_fp6_block_scaled_corrections_within_1e_3_of_torch_at_trained_logit_scale(oracle, arch, n, blocks, batch):
+    """TZ_PREC_F16C6 on the same weights: the fp16 product wh*xh plus the correction products wl*xh + wh*xl on FP6 (E2M3) copies of the
+    operands with one power-of-two scale per block of 32 input channels (v_mfma_scale_f32_16x16x128_f8f6f4), the blocks' inputs
+    carried in fp32 between the two convs of a block, value / UBE heads on the fp32 tower output.  Same absolute 1e-3 on policy,
+    value and UBE against the fp32 LibTorch graph (net5.rs:184-191,237-238); measured 1.4e-4 on net5 like TZ_PREC_F16C8."""
+    A = require_gpu()
+    err = _compare(A, oracle, arch, n, blocks, A.PREC_F16C6, batch, 45, True, trained_scale=True)
+    print("f16c6 errors (trained scale)", err)
+    assert 7.9 < err["scale"] < 8.1
+    assert err["policy"] < F32_TOL and err["value"] < F32_TOL and err["ube"] < F32_TOL
+    assert err["policy"] < 5e-4 and err["value"] < 2e-4 and err["ube"] < 2e-4
+
+
+def test_f16c6_is_much_closer_than_fp16_at_random_init_scale_too(oracle):
+    """At random-init scale (|logit| ~ 0.2) the fp16 default is 1.5e-4 off the fp32 graph; the corrections bring that to a few 1e-6."""
+    A = require_gpu()
+    err = _compare(A, oracle, 5, 5, 20, A.PREC_F16C6, 10, 123, False)
+    print("f16c6 errors (random init)", err)
+    assert err["policy"] < 2e-5 and err["value"] < 2e-5 and err["ube"] < 2e-5
+
+
+def test_f16c6_large_activations_stay_finite(oracle):
+    """Activations in the thousands: the E2M3 copies are block-scaled (no fixed range to leave), stored halves saturate at 65504."""
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    w = dict(W.init_weights(W.ARCH_TEST, n=5, blocks=2, seed=3, trained_stats=True))
+    w["core.batch_norm.weight"] = (np.asarray(w["core.batch_norm.weight"], np.float32) * np.float32(3000.0)).astype(np.float32)
+    states = O.states_array(random_positions(oracle, O, 5, 4, 16, 5))
+    outs = {}
+    for prec in (A.PREC_F32, A.PREC_F16C6):
+        net = A.Net(arch=A.ARCH_TEST, n=5, precision=prec, blocks=2)
+        net.load_tensors(w)
+        outs[prec] = net.forward_raw(states)
+        net.close()
+    pol, val, ube = outs[A.PREC_F16C6]
+    assert np.isfinite(pol).all() and np.isfinite(val).all() and np.isfinite(ube).all()
+    scale = float(np.abs(outs[A.PREC_F32][0]).max())
+    print("large activations: |logit| max", scale, "max error", float(np.abs(pol - outs[A.PREC_F32][0]).max()))
+    assert float(np.abs(pol - outs[A.PREC_F32][0]).max()) < 1e-4 * scale
+
+
+def test_f16c6_is_refused_on_board_sizes_it_is_not_built_for():
+    A = require_gpu()
+    with pytest.raises(Exception):
+        A.Net(arch=A.ARCH_TEST, n=4, precision=A.PREC_F16C6, blocks=2)
+
+
 @pytest.mark.parametrize("arch,n,blocks,batch", NETS)
 def test_f16_default_at_trained_logit_scale_is_relative(oracle, arch, n, blocks, batch):
     """The fp16 throughput default on the same trained-scale weights: its error is relative (~2e-4 of the logit scale
@@ -187,7 +239,7 @@ def test_f32_path_at_trained_logit_scale(oracle):
     assert err["policy"] < 1e-4 and err["value"] < 1e-4 and err["ube"] < 1e-4
 
 
-@pytest.mark.parametrize("prec,n", [(0, 5), (2, 5), (3, 5), (3, 6), (3, 4), (3, 3), (4, 5), (4, 6), (4, 4), (4, 3)])
+@pytest.mark.parametrize("prec,n", [(0, 5), (2, 5), (3, 5), (3, 6), (3, 4), (3, 3), (4, 5), (4, 6), (4, 4), (4, 3), (5, 5), (5, 6)])
 def test_forward_is_batch_composition_independent(oracle, prec, n):
     """A position's outputs do not depend on its slot or its neighbours (needed so that the oracle can
     replay the engine's network calls one position at a time): bf16, fp16, the split-precision kernel and the FP8-correction
@@ -208,7 +260,7 @@ def test_forward_is_batch_composition_independent(oracle, prec, n):
         assert np.array_equal(pol[perm], pol2) and np.array_equal(val[perm], val2) and np.array_equal(ube[perm], ube2), count
 
 
-@pytest.mark.parametrize("prec", [3, 4])
+@pytest.mark.parametrize("prec", [3, 4, 5])
 def test_workgroup_forms_of_the_split_precisions_on_6x6_give_the_same_bits(oracle, prec):
     """6x6 in a split precision: 2 boards per workgroup (board-major rows) below 1024 positions, 4 boards (square-major rows, 12 of
     81 (tap, tile) pairs skipped, tap table of 8-bit rows) from there on - the same bits for a position either way."""
@@ -227,7 +279,7 @@ def test_workgroup_forms_of_the_split_precisions_on_6x6_give_the_same_bits(oracl
     net.close()
 
 
-@pytest.mark.parametrize("prec", [2, 4])
+@pytest.mark.parametrize("prec", [2, 4, 5])
 def test_workgroup_forms_give_the_same_bits(oracle, prec):
     """Small batches run on 1- and 2-board workgroups (board-major rows), large ones on 8 (fp16) or 4 (fp16 + FP8 corrections)
     boards in square-major order with the all-padding (tap, tile) pairs left out: a position's outputs are the same bits in
