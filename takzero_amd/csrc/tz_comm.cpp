@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -72,7 +73,9 @@ Rccl* rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) candidates.push_back(name);
     std::string rejected;
     for (const std::string& name : candidates) {
-        void* h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        // RTLD_LOCAL: if a second librccl is mapped later (PyTorch ships its own and loads it with `import torch`), its symbols
+        // and this copy's must not interpose - that mix is what aborted at exit with a double free (tools/rccl_copies_check.py torch_after)
+        void* h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!h) continue;
         if (same_hip_runtime(h)) {
             r.handle = h;
@@ -106,6 +109,41 @@ Rccl* rccl() {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Rendezvous files in a directory that outlives the job (selfplay's data directory): rank 0 replaces whatever is there and removes its
+// file once everybody has used it; the other ranks take a file only if it is not older than their own start minus a slack, so what
+// a crashed job left behind is not mistaken for this job's.
+const time_t g_process_start = time(nullptr);
+constexpr time_t STALE_SLACK_S = 300;
+std::string g_published_id_path;   // rank 0: the id file to remove once its communicator is up
+
+int publish_fresh(const std::string& path, const void* data, size_t n) {
+    (void)unlink(path.c_str());
+    const std::string tmp = path + ".part";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(data, 1, n, f) != n) {
+        if (f) fclose(f);
+        return tz_fail(TZ_EINVAL, "comm: cannot write " + tmp);
+    }
+    fclose(f);
+    if (rename(tmp.c_str(), path.c_str())) return tz_fail(TZ_EINVAL, "comm: cannot publish " + path);
+    return TZ_OK;
+}
+
+int read_fresh(const std::string& path, void* out, size_t n, double timeout_s) {
+    const double t0 = now_s();
+    for (;;) {
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == n && st.st_mtime + STALE_SLACK_S >= g_process_start) {
+            FILE* f = fopen(path.c_str(), "rb");
+            const size_t got = f ? fread(out, 1, n, f) : 0;
+            if (f) fclose(f);
+            if (got == n) return TZ_OK;
+        }
+        if (now_s() - t0 > timeout_s) return tz_fail(TZ_ESTATE, "comm: rank 0 did not publish " + path + " (a file older than this process does not count)");
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+}
+
 }  // namespace
 
 struct tz_comm {
@@ -119,6 +157,7 @@ struct tz_comm {
     size_t send_cap = 0, recv_cap = 0;
     // fs
     std::string dir;
+    uint64_t nonce = 0;   // of this job (rank 0 draws it, xch-job.bin carries it): the exchange files of another job never match
     uint64_t seq = 0;
     double timeout_s = 600.0;
     uint64_t bytes_gathered = 0, collectives = 0;
@@ -156,7 +195,9 @@ int all_gather_fixed(tz_comm* c, const void* mine, size_t bytes, unsigned char* 
     }
     if (c->fs) {
         const uint64_t seq = c->seq++;
-        auto name = [&](uint64_t s, int r) { return c->dir + "/xch-" + std::to_string(s) + "-" + std::to_string(r) + ".bin"; };
+        char tag[24];
+        snprintf(tag, sizeof tag, "%016llx", (unsigned long long)c->nonce);
+        auto name = [&](uint64_t s, int r) { return c->dir + "/xch-" + tag + "-" + std::to_string(s) + "-" + std::to_string(r) + ".bin"; };
         const std::string tmp = name(seq, c->rank) + ".part";
         FILE* f = fopen(tmp.c_str(), "wb");
         if (!f || fwrite(mine, 1, bytes, f) != bytes) {
@@ -259,26 +300,11 @@ int tz_comm_rendezvous_id(const char* directory, int rank, unsigned char* id_ino
     if (rank == 0) {
         int rc = tz_comm_unique_id(id_inout);
         if (rc) return rc;
-        FILE* f = fopen((path + ".part").c_str(), "wb");
-        if (!f || fwrite(id_inout, 1, TZ_COMM_ID_BYTES, f) != TZ_COMM_ID_BYTES) {
-            if (f) fclose(f);
-            return tz_fail(TZ_EINVAL, "tz_comm_rendezvous_id: cannot write " + path);
-        }
-        fclose(f);
-        if (rename((path + ".part").c_str(), path.c_str())) return tz_fail(TZ_EINVAL, "tz_comm_rendezvous_id: cannot publish " + path);
+        if ((rc = publish_fresh(path, id_inout, TZ_COMM_ID_BYTES))) return rc;   // whatever an earlier job left there is gone first
+        g_published_id_path = path;
         return TZ_OK;
     }
-    const double t0 = now_s();
-    for (;;) {
-        FILE* f = fopen(path.c_str(), "rb");
-        if (f) {
-            const size_t got = fread(id_inout, 1, TZ_COMM_ID_BYTES, f);
-            fclose(f);
-            if (got == TZ_COMM_ID_BYTES) return TZ_OK;
-        }
-        if (now_s() - t0 > timeout_s) return tz_fail(TZ_ESTATE, "tz_comm_rendezvous_id: rank 0 did not publish " + path);
-        std::this_thread::sleep_for(std::chrono::milliseconds(5));
-    }
+    return read_fresh(path, id_inout, TZ_COMM_ID_BYTES, timeout_s);
 }
 
 int tz_comm_create_rccl(const unsigned char* id, int rank, int world, int device_id, tz_comm** out) {
@@ -305,6 +331,10 @@ int tz_comm_create_rccl(const unsigned char* id, int rank, int world, int device
         delete c;
         return tz_fail(TZ_EDEVICE, "tz_comm_create_rccl: hipStreamCreate failed");
     }
+    if (rank == 0 && !g_published_id_path.empty()) {   // every rank has joined with it: a later job in this directory must not find it
+        (void)unlink(g_published_id_path.c_str());
+        g_published_id_path.clear();
+    }
     *out = c;
     return TZ_OK;
 }
@@ -317,6 +347,20 @@ int tz_comm_create_fs(const char* directory, int rank, int world, double timeout
     c->fs = true;
     c->dir = directory;
     if (timeout_s > 0) c->timeout_s = timeout_s;
+    if (world > 1) {   // the job's nonce: drawn by rank 0, published fresh (a leftover xch-job.bin is replaced / not accepted when stale)
+        const std::string job = c->dir + "/xch-job.bin";
+        int rc;
+        if (rank == 0) {
+            c->nonce = ((uint64_t)std::chrono::system_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)getpid() << 32);
+            rc = publish_fresh(job, &c->nonce, sizeof c->nonce);
+        } else {
+            rc = read_fresh(job, &c->nonce, sizeof c->nonce, c->timeout_s);
+        }
+        if (rc) {
+            delete c;
+            return rc;
+        }
+    }
     *out = c;
     return TZ_OK;
 }
@@ -325,7 +369,8 @@ int tz_comm_destroy(tz_comm* c) {
     if (!c) return TZ_OK;
     if (c->fs) {
         // a closing round: once it completes every rank has read my last payload, which the round then deletes; what stays
-        // behind is this round's 8 bytes per rank (nobody can know that the others have read those: use a fresh directory per job)
+        // behind is this round's 8 bytes per rank (nobody can know that the others have read those) under this job's nonce,
+        // which no later job in the directory uses
         if (c->world > 1 && c->seq >= 1) {
             uint64_t one = 1;
             std::vector<uint64_t> all(c->world);

@@ -63,26 +63,28 @@ int zip_entries(const unsigned char* d, size_t n, std::vector<ZipEntry>& out) {
     uint64_t count = rd16(d + eocd + 10), cd_size = rd32(d + eocd + 12), cd_off = rd32(d + eocd + 16);
     if (eocd >= 20 && rd32(d + eocd - 20) == 0x07064b50u) {   // zip64 locator in front of it (LibTorch always writes one)
         const uint64_t z64 = rd64(d + eocd - 20 + 8);
-        if (z64 + 56 <= n && rd32(d + z64) == 0x06064b50u) {
+        if (z64 <= n && n - z64 >= 56 && rd32(d + z64) == 0x06064b50u) {   // (no sums of file-supplied 64-bit values: they can wrap)
             count = rd64(d + z64 + 32);
             cd_size = rd64(d + z64 + 40);
             cd_off = rd64(d + z64 + 48);
         }
     }
-    if (cd_off + cd_size > n) return tz_fail(TZ_EPARSE, "model archive: central directory outside the file");
+    if (cd_off > n || cd_size > n - cd_off) return tz_fail(TZ_EPARSE, "model archive: central directory outside the file");
+    if (count > cd_size / 46) return tz_fail(TZ_EPARSE, "model archive: more central directory entries than the directory can hold");
     size_t p = cd_off;
     for (uint64_t i = 0; i < count; i++) {
-        if (p + 46 > n || rd32(d + p) != 0x02014b50u) return tz_fail(TZ_EPARSE, "model archive: bad central directory entry");
+        if (p > n || n - p < 46 || rd32(d + p) != 0x02014b50u) return tz_fail(TZ_EPARSE, "model archive: bad central directory entry");
         ZipEntry e;
         e.method = rd16(d + p + 10);
         e.csize = rd32(d + p + 20);
         e.usize = rd32(d + p + 24);
         const size_t fl = rd16(d + p + 28), xl = rd16(d + p + 30), cl = rd16(d + p + 32);
         uint64_t lho = rd32(d + p + 42);
-        if (p + 46 + fl + xl + cl > n) return tz_fail(TZ_EPARSE, "model archive: truncated central directory");
+        if (fl + xl + cl > n - p - 46) return tz_fail(TZ_EPARSE, "model archive: truncated central directory");
         e.name.assign((const char*)d + p + 46, fl);
         for (size_t x = p + 46 + fl; x + 4 <= p + 46 + fl + xl;) {   // zip64 extended information
             const uint16_t id = rd16(d + x), len = rd16(d + x + 2);
+            if ((size_t)len > p + 46 + fl + xl - (x + 4)) return tz_fail(TZ_EPARSE, "model archive: extra field of " + e.name + " runs past its header");
             if (id == 1) {
                 size_t q = x + 4;
                 if (e.usize == 0xFFFFFFFFu && q + 8 <= x + 4 + len) e.usize = rd64(d + q), q += 8;
@@ -91,9 +93,9 @@ int zip_entries(const unsigned char* d, size_t n, std::vector<ZipEntry>& out) {
             }
             x += 4 + (size_t)len;
         }
-        if (lho + 30 > n || rd32(d + lho) != 0x04034b50u) return tz_fail(TZ_EPARSE, "model archive: bad local header of " + e.name);
+        if (lho > n || n - lho < 30 || rd32(d + lho) != 0x04034b50u) return tz_fail(TZ_EPARSE, "model archive: bad local header of " + e.name);
         e.offset = lho + 30 + rd16(d + lho + 26) + rd16(d + lho + 28);
-        if (e.offset + e.csize > n) return tz_fail(TZ_EPARSE, "model archive: entry " + e.name + " runs past the end of the file");
+        if (e.offset > n || e.csize > n - e.offset) return tz_fail(TZ_EPARSE, "model archive: entry " + e.name + " runs past the end of the file");
         if (e.method == 0 && e.usize != e.csize) return tz_fail(TZ_EPARSE, "model archive: stored entry " + e.name + " with two different sizes");
         out.push_back(e);
         p += 46 + fl + xl + cl;
@@ -132,7 +134,7 @@ int unpickle(const unsigned char* d, size_t n, P& root) {
     std::vector<P> st;
     std::map<uint32_t, P> memo;
     size_t p = 0;
-    auto need = [&](size_t k) { return p + k <= n; };
+    auto need = [&](size_t k) { return k <= n - p; };   // p <= n always; a length from the file may be anything up to 2^64 - 1
     auto pop_to_mark = [&](std::vector<P>& out) -> bool {
         size_t m = st.size();
         while (m > 0 && st[m - 1]->kind != PV::MARK) m--;
@@ -456,7 +458,7 @@ bool bn_stats_first() {   // see ot_tch_names
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ API
-int ot_read_archive(const unsigned char* data, size_t bytes, NamedTensors& out) {
+static int ot_read_archive_impl(const unsigned char* data, size_t bytes, NamedTensors& out) {
     std::vector<ZipEntry> entries;
     int rc = zip_entries(data, bytes, entries);
     if (rc) return rc;
@@ -491,6 +493,7 @@ int ot_read_archive(const unsigned char* data, size_t bytes, NamedTensors& out) 
         for (auto dv : v->dims) {
             if (dv < 0) return tz_fail(TZ_EPARSE, "model archive: negative dimension in " + k->s);
             t.dims.push_back((uint32_t)dv);
+            if (dv != 0 && total > (numel_storage + 1) / (uint64_t)dv + 1) return tz_fail(TZ_EPARSE, "model archive: tensor " + k->s + " is larger than its storage");
             total *= (uint64_t)dv;
         }
         // a variable is a view of its own storage: more elements than the storage holds means a damaged size tuple (and must not
@@ -685,33 +688,55 @@ void ot_tch_names(const TensorStore& in, NamedTensors& out) {
         if (kv.first.compare(0, 5, "core.") && !done.count(kv.first)) add(kv.first, kv.first);
 }
 
-int tzw_parse(const unsigned char* p, size_t bytes, TensorStore& out) {
+static int tzw_parse_impl(const unsigned char* p, size_t bytes, TensorStore& out) {
     if (bytes < 8 || memcmp(p, "TZW1", 4)) return tz_fail(TZ_EPARSE, "weights: bad magic");
     const uint32_t count = rd32(p + 4);
     size_t off = 8;
     for (uint32_t i = 0; i < count; i++) {
-        if (off + 2 > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        if (off > bytes || bytes - off < 2) return tz_fail(TZ_EPARSE, "weights: truncated");
         const uint16_t ln = rd16(p + off);
         off += 2;
-        if (off + ln + 1 > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        if ((size_t)ln + 1 > bytes - off) return tz_fail(TZ_EPARSE, "weights: truncated");
         std::string name((const char*)p + off, ln);
         off += ln;
         const int nd = p[off++];
         HostTensor t;
         size_t size = 1;
-        if (off + 4 * (size_t)nd > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        if (4 * (size_t)nd > bytes - off) return tz_fail(TZ_EPARSE, "weights: truncated");
         for (int d = 0; d < nd; d++) {
             t.dims.push_back(rd32(p + off));
+            // the product may not pass what the rest of the blob can hold (and so cannot wrap either)
+            if (t.dims.back() != 0 && size > (bytes / 4) / t.dims.back()) return tz_fail(TZ_EPARSE, "weights: tensor " + name + " larger than the blob");
             size *= t.dims.back();
             off += 4;
         }
-        if (off + 4 * size > bytes) return tz_fail(TZ_EPARSE, "weights: truncated");
+        if (size > (bytes - off) / 4) return tz_fail(TZ_EPARSE, "weights: truncated");
         t.data.resize(size);
         memcpy(t.data.data(), p + off, 4 * size);
         off += 4 * size;
         out[name] = std::move(t);
     }
     return TZ_OK;
+}
+
+// The parsers are reached from the C ABI (tz_net_load_weights, tz_net_load_weights_mem, tz_net_broadcast's blobs): nothing a file
+// can hold may leave them as an exception - a length the checks above let through that still cannot be allocated is TZ_ENOMEM, not
+// a terminate() across extern "C".
+template <typename F>
+static int guarded(const char* what, F f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return tz_fail(TZ_ENOMEM, std::string(what) + ": out of memory");
+    } catch (const std::exception& e) {
+        return tz_fail(TZ_EPARSE, std::string(what) + ": " + e.what());
+    }
+}
+int ot_read_archive(const unsigned char* data, size_t bytes, NamedTensors& out) {
+    return guarded("model archive", [&] { return ot_read_archive_impl(data, bytes, out); });
+}
+int tzw_parse(const unsigned char* p, size_t bytes, TensorStore& out) {
+    return guarded("weights", [&] { return tzw_parse_impl(p, bytes, out); });
 }
 
 void tzw_dump(const TensorStore& in, std::vector<unsigned char>& o) {

@@ -2,8 +2,8 @@
 
 Each line of runs/puct.txt lists the root children of one 5x5 position as
 `move:visits:eval:std_dev` in child order = fast-tak `possible_moves` order.
-We keep only the move names of every 8th line (128 positions): that is the one in-tree artefact
-that pins fast-tak's move ordering.  Run in the build container: python tests/golden/make_runs_fixture.py
+We keep the move names of all 1024 lines (1005 distinct move lists; round 2 kept every 8th): the one in-tree
+artefact that pins fast-tak's move ordering.  Run in the build container: python tests/golden/make_runs_fixture.py
 """
 import os
 
@@ -12,8 +12,6 @@ DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "runs_puct_move_o
 
 with open(SRC) as f, open(DST, "w") as out:
     for i, line in enumerate(f):
-        if i % 8:
-            continue
         moves = [rec.split(":")[0] for rec in line.strip().split(",") if rec]
         out.write(" ".join(moves) + "\n")
 print("wrote", DST)

@@ -26,6 +26,20 @@ def test_rccl_communicator_in_clean_processes():
         assert "[b'abc']" in r.stdout and "'transport': 'rccl'" in r.stdout
 
 
+def test_torch_imported_after_the_communicator_does_not_abort():
+    """The load order that maps two RCCL copies (the library opens the system's, `import torch` brings PyTorch's afterwards) used to
+    abort at interpreter exit with a double free: the library's copy is opened RTLD_LOCAL, so the two do not interpose."""
+    import os
+    import subprocess
+    import sys
+
+    require_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_copies_check.py"), "torch_after"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "[b'abc']" in r.stdout and "'transport': 'rccl'" in r.stdout
+
+
 def test_rccl_communicator_of_one_rank(tmp_path):
     """ncclCommInitRank / ncclAllGather / ncclBroadcast at world 1, the model hand-over and the self-play driver on top of
     them: in a process of its own (tests/comm_world1_script.py) that imports torch first, as bench.py does under torchrun — this

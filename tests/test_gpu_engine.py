@@ -78,7 +78,7 @@ def test_gumbel_search_at_trained_scale_agrees_with_the_fp32_path():
     rng = np.random.default_rng(3)
     gumbel = rng.gumbel(size=(B, 512)).astype(np.float32)      # one draw per child, in possible_moves order
     results = {}
-    for name in ("f32", "f16x2", "f16c8", "f16"):
+    for name in ("f32", "f16x2", "f16c8", "f16c6", "f16"):
         net = A.Net(arch=A.ARCH_NET5, precision=A.PREC_NAMES[name]).load_tensors(w)
         mcts = A.BatchedMCTS(B, n, 4, agent=net, node_capacity=1 << 14)
         mcts.set_positions(np.arange(B), states)
@@ -88,7 +88,8 @@ def test_gumbel_search_at_trained_scale_agrees_with_the_fp32_path():
         mcts.close()
         net.close()
     ref_top, ref_vis = results["f32"]
-    for name, min_same, min_identical in (("f16x2", 0.99, 0.97), ("f16c8", 0.98, 0.94), ("f16", 0.0, 0.0)):
+    # the fp16 default is gated too, below what round 2 measured for it (0.93 / 0.61), so that a regression of it shows
+    for name, min_same, min_identical in (("f16x2", 0.99, 0.97), ("f16c8", 0.98, 0.94), ("f16c6", 0.98, 0.94), ("f16", 0.85, 0.45)):
         top, vis = results[name]
         same = float((top == ref_top).mean())
         identical = float((vis == ref_vis).all(1).mean())
@@ -99,8 +100,8 @@ def test_gumbel_search_at_trained_scale_agrees_with_the_fp32_path():
 @pytest.mark.parametrize("scale,B,gates", [
     # (precision, min fraction of games with the same chosen move, min fraction with identical visit counts at every root child,
     #  max mean total-variation distance of the visit distributions)
-    ("random-init", 512, (("f16x2", 0.995, 0.98, 0.002), ("f16c8", 0.995, 0.97, 0.003), ("f16", 0.98, 0.95, 0.02), ("bf16", 0.90, 0.85, 0.10))),
-    ("trained", 128, (("f16x2", 0.99, 0.97, 0.005), ("f16c8", 0.99, 0.95, 0.008), ("f16", 0.90, 0.50, 0.10))),
+    ("random-init", 512, (("f16x2", 0.995, 0.98, 0.002), ("f16c8", 0.995, 0.97, 0.003), ("f16c6", 0.995, 0.97, 0.003), ("f16", 0.98, 0.95, 0.02), ("bf16", 0.90, 0.85, 0.10))),
+    ("trained", 128, (("f16x2", 0.99, 0.97, 0.005), ("f16c8", 0.99, 0.95, 0.008), ("f16c6", 0.99, 0.95, 0.008), ("f16", 0.90, 0.50, 0.10))),
 ])
 def test_search_with_the_mfma_nets_agrees_with_the_fp32_path_on_moves_and_visits(scale, B, gates):
     """North star: visit counts and chosen moves match the reference's fp32 path.  Bit-exactness of the tree is proven

@@ -260,9 +260,41 @@ def test_native_reader_under_sanitizers_on_damaged_archives(tmp_path):
         path = tmp_path / ("bad%03d.ot" % i)
         path.write_bytes(bytes(b))
         files.append(str(path))
+    # targeted: 64-bit sizes and offsets chosen so that a bounds check written as a sum wraps around - the zip64 records'
+    # directory offset / size / count, a zip64 locator pointing near 2^64, an 8-byte string length in the pickle, huge tensor
+    # dimensions in the flat container
+    import struct
+
+    count, cd_size, cd_off = struct.unpack("<HII", bytes(blob[eocd_at + 10:eocd_at + 20]))
+    z64_at = eocd_at                                                   # a zip64 end record + locator in front of the end record,
+    z64 = (b"PK\x06\x06" + struct.pack("<QHHIIQQQQ", 44, 45, 45, 0, 0, count, count, cd_size, cd_off) +   # as LibTorch writes them
+           b"PK\x06\x07" + struct.pack("<IQI", 0, z64_at, 1))
+    blob64 = bytearray(blob[:eocd_at] + z64 + blob[eocd_at:])
+    loc_at = z64_at + 56
+    targeted = [bytes(blob64)]                                          # (the intact zip64 form must still load)
+    for off, val in ((48, 2 ** 64 - 10), (40, 2 ** 64 - 1), (32, 2 ** 63), (48, len(blob64) - 5), (40, 2 ** 40)):
+        b = bytearray(blob64)
+        b[z64_at + off:z64_at + off + 8] = struct.pack("<Q", val)      # count (32), directory size (40), directory offset (48)
+        targeted.append(bytes(b))
+    for val in (2 ** 64 - 56, 2 ** 64 - 1, len(blob64)):
+        b = bytearray(blob64)
+        b[loc_at + 8:loc_at + 16] = struct.pack("<Q", val)             # where the zip64 end record is said to be
+        targeted.append(bytes(b))
+    b = bytearray(blob)
+    x_at = bytes(b).index(b"X", pkl_at)                                # a BINUNICODE: turn it into BINUNICODE8 with a length of 2^64 - 3
+    b[x_at:x_at + 5] = b"\x8d" + struct.pack("<I", 0xFFFFFFFD)
+    b[x_at + 5:x_at + 9] = b"\xff\xff\xff\xff"
+    targeted.append(bytes(b))
+    for dims in ((2 ** 31, 2 ** 31, 4), (2 ** 32 - 1, 2 ** 32 - 1), (2 ** 30, 16)):
+        t = b"TZW1" + struct.pack("<I", 1) + struct.pack("<H", 1) + b"w" + bytes([len(dims)]) + b"".join(struct.pack("<I", d) for d in dims) + b"\0" * 64
+        targeted.append(t)
+    for i, data in enumerate(targeted):
+        path = tmp_path / ("wrap%02d.ot" % i)
+        path.write_bytes(data)
+        files.append(str(path))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1")
     out = subprocess.run([exe] + files, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, (out.stdout[-300:], out.stderr[-3000:])
     fields = dict(zip(out.stdout.split()[::2], out.stdout.split()[1::2]))
-    assert int(fields["ok"]) >= 1 and int(fields["other"]) == 0 and int(fields["ok"]) + int(fields["parse_errors"]) == len(files)
+    assert int(fields["ok"]) >= 2 and int(fields["other"]) == 0 and int(fields["ok"]) + int(fields["parse_errors"]) == len(files)
     assert int(fields["parse_errors"]) > 150 and eocd_at > cd_at
