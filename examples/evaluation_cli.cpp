@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = atoi(next());
         else if (a == "--bf16") precision = TZ_PREC_BF16;
         else if (a == "--f16c8") precision = TZ_PREC_F16C8;
+        else if (a == "--f16c6") precision = TZ_PREC_F16C6;
         else if (a == "--f16x2") precision = TZ_PREC_F16X2;
         else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -103,7 +104,7 @@ int main(int argc, char** argv) {
     }
     if (model_path.empty()) {
         fprintf(stderr, "usage: evaluation_cli --model-path DIR [--step K --opening-book FILE --arch 4|5|6|100 --n N --blocks K --games 64 "
-                        "--sampled-actions 64 --budget 768 --max-moves 200 --rounds R --seed X --sleep SECONDS --device G --bf16|--f16c8|--f16x2]\n");
+                        "--sampled-actions 64 --budget 768 --max-moves 200 --rounds R --seed X --sleep SECONDS --device G --bf16|--f16c6|--f16c8|--f16x2]\n");
         return 2;
     }
     if (arch == TZ_ARCH_NET5) n = 5;

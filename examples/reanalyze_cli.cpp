@@ -37,18 +37,29 @@ static int reload_model(void* user) {
     const bool changed = !(st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size && (long long)st.st_ino == r->inode);
     if (r->async) {
         if (r->preparing.valid() && r->preparing.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
+            bool placed = false;
             if (tz_pending_weights* p = r->preparing.get()) {
-                if (tz_net_load_commit(r->net, p) == 0) r->reloads++;
-                else fprintf(stderr, "Cannot put the model in place: %s\n", tz_last_error());
+                if (tz_net_load_commit(r->net, p) == 0) {
+                    r->reloads++;
+                    placed = true;
+                } else {
+                    fprintf(stderr, "Cannot put the model in place: %s\n", tz_last_error());
+                }
+            }
+            if (!placed) {   // a torn or missing file: forget its stamp, so that the file is prepared again below (the synchronous road's retry)
+                r->stamp_s = r->stamp_ns = -1;
+                r->size = -1;
+                r->inode = -1;
             }
         }
-        if (changed && !r->preparing.valid()) {
+        const bool again = !(st.st_mtim.tv_sec == r->stamp_s && st.st_mtim.tv_nsec == r->stamp_ns && st.st_size == r->size && (long long)st.st_ino == r->inode);
+        if (again && !r->preparing.valid()) {
             tz_net* net = r->net;
             const std::string path = r->path;
             r->preparing = std::async(std::launch::async, [net, path]() -> tz_pending_weights* {
                 tz_pending_weights* p = nullptr;
                 if (tz_net_load_prepare(net, path.c_str(), &p) != 0) {
-                    fprintf(stderr, "Cannot load model: %s, retrying when the file changes.\n", tz_last_error());
+                    fprintf(stderr, "Cannot load model: %s, retrying.\n", tz_last_error());
                     return nullptr;
                 }
                 return p;
@@ -111,6 +122,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = atoi(next());
         else if (a == "--f16x2") precision = TZ_PREC_F16X2;
         else if (a == "--f16c8") precision = TZ_PREC_F16C8;
+        else if (a == "--f16c6") precision = TZ_PREC_F16C6;
         else if (a == "--bf16") precision = TZ_PREC_BF16;
         else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -120,7 +132,7 @@ int main(int argc, char** argv) {
     if (directory.empty()) {
         fprintf(stderr, "usage: reanalyze_cli --directory DIR [--model FILE --watch model_latest.ot --arch 4|5|6|100 --n N --blocks K --games B "
                         "--sims S --search puct|gumbel --sampled-actions K --iterations I --min-positions P --wait-limit SECONDS --seed X "
-                        "--rank R --world N --device G --async-reload --bf16|--f16c8|--f16x2]\n");
+                        "--rank R --world N --device G --async-reload --bf16|--f16c6|--f16c8|--f16x2]\n");
         return 2;
     }
     if (arch == TZ_ARCH_NET5) n = 5;

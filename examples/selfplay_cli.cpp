@@ -129,6 +129,7 @@ int main(int argc, char** argv) {
         else if (a == "--comm-dir") comm_dir = next();
         else if (a == "--f16x2") precision = TZ_PREC_F16X2;
         else if (a == "--f16c8") precision = TZ_PREC_F16C8;
+        else if (a == "--f16c6") precision = TZ_PREC_F16C6;
         else if (a == "--f16") precision = TZ_PREC_F16;
         else if (a == "--bf16") precision = TZ_PREC_BF16;
         else if (a == "--exploration") exploration = 1;
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
     }
     if (directory.empty() || (world > 1 && comm_kind != "rccl" && comm_kind != "fs")) {
         fprintf(stderr, "usage: selfplay_cli --directory DIR [--model FILE.ot|.tzw --watch model_latest.ot --arch 4|5|6|100 --n N --blocks K "
-                        "--games B --sims S --search puct|gumbel --sampled-actions K --moves M --exploration --async-reload --f16|--bf16|--f16c8|--f16x2 "
+                        "--games B --sims S --search puct|gumbel --sampled-actions K --moves M --exploration --async-reload --f16|--bf16|--f16c6|--f16c8|--f16x2 "
                         "--wait-limit SECONDS --seed X] [--rank R --world N --comm rccl|fs --comm-dir D --device G]\n");
         return 2;
     }

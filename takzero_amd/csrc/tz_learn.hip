@@ -100,29 +100,37 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
-    float4 ra = GATHER ? gather() : *(const float4*)ap, rb = *(const float4*)bp;
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += 32, buf ^= 1) {
+    // operands of k-steps i and i + 1 are in flight while step i - 1 multiplies: one step (a thousand cycles) does not cover a
+    // miss of the XCD's L2 on the gathered view, two do
+    float4 ra[2], rb[2];
+    auto fetch = [&](int slot) {
+        ra[slot] = GATHER ? gather() : *(const float4*)ap;
+        rb[slot] = *(const float4*)bp;
+    };
+    auto advance = [&]() {
+        bp += bstep;
+        if (GATHER) gather_advance();
+        else ap += astep;
+    };
+    fetch(0);
+    if (32 < K) {
+        advance();
+        fetch(1);
+    }
+    auto step = [&](int k0, int buf, int slot) {
         if (AT) {
-            *(float4*)&As[buf][g][ak][am] = ra;
+            *(float4*)&As[buf][g][ak][am] = ra[slot];
         } else {
-            As[buf][g][ak + 0][am] = ra.x;
-            As[buf][g][ak + 1][am] = ra.y;
-            As[buf][g][ak + 2][am] = ra.z;
-            As[buf][g][ak + 3][am] = ra.w;
+            As[buf][g][ak + 0][am] = ra[slot].x;
+            As[buf][g][ak + 1][am] = ra[slot].y;
+            As[buf][g][ak + 2][am] = ra[slot].z;
+            As[buf][g][ak + 3][am] = ra[slot].w;
         }
-        *(float4*)&Bs[buf][g][bk][bn] = rb;
+        *(float4*)&Bs[buf][g][bk][bn] = rb[slot];
         __syncthreads();
-        if (k0 + 32 < K) {
-            bp += bstep;
-            if (GATHER) {
-                gather_advance();
-                ra = gather();
-            } else {
-                ap += astep;
-                ra = *(const float4*)ap;
-            }
-            rb = *(const float4*)bp;
+        if (k0 + 64 < K) {
+            advance();
+            fetch(slot);
         }
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
@@ -130,6 +138,10 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
             const float b = Bs[buf][g][kk + (lane >> 5)][wn + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+    };
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        step(k0, 0, 0);
+        if (k0 + 32 < K) step(k0 + 32, 1, 1);
     }
     __syncthreads();
     float* red = &As[0][0][0][0];  // 64 x 64 partial tile of group 1

@@ -2885,6 +2885,14 @@ int build_weights(tz_net* net, const TensorMap& m, NetWeights& W) {
                 return;
             }
             std::unique_ptr<UploadStream> upload_stream(background ? new UploadStream() : nullptr);
+            if (upload_stream && !upload_stream->mine) {   // no stream of its own: a legacy-stream copy would break the search thread's capture
+                std::lock_guard<std::mutex> lk(mu);
+                if (failed == TZ_OK) {
+                    failed = TZ_EDEVICE;
+                    first_error = "weights: cannot create an upload stream for a build thread";
+                }
+                return;
+            }
             std::vector<float> lw, lscale, lbias;
             for (int l = next++; l < nl && failed == TZ_OK; l = next++) {
                 const std::string p = "core.res_block_" + std::to_string(l / 2) + ((l & 1) ? ".b" : ".a");
@@ -3706,6 +3714,10 @@ static int net_prepare_store(tz_net* net, TensorStore&& store, tz_pending_weight
     p->net = net;
     const TensorMap m = view_of(p->store);
     std::unique_ptr<UploadStream> upload_stream(background ? new UploadStream() : nullptr);
+    if (upload_stream && !upload_stream->mine) {   // never fall back to the legacy stream beside a running search (see UploadStream)
+        delete p;
+        return tz_fail(TZ_EDEVICE, "tz_net_load_prepare: cannot create the upload stream");
+    }
     const int rc = build_weights(net, m, p->W);
     if (rc) {
         free_weights(p->W);
@@ -4024,12 +4036,16 @@ int tz_net_broadcast(tz_net* net, tz_comm* c, int root, int status) {
     int64_t head[2] = {status, 0};
     std::vector<unsigned char> blob;
     if (rank == root && status == 0) {
-        if (!net->loaded) return tz_fail(TZ_ESTATE, "tz_net_broadcast: the root network has no weights");
-        tzw_dump(net->store, blob);
-        head[1] = (int64_t)blob.size();
+        // a root without weights says so in the header: every rank leaves with the same error, nobody is left inside the collective
+        if (!net->loaded) head[0] = -1;
+        else {
+            tzw_dump(net->store, blob);
+            head[1] = (int64_t)blob.size();
+        }
     }
     rc = tz_comm_broadcast(c, head, sizeof head, root);
     if (rc) return rc;
+    if (head[0] == -1) return tz_fail(TZ_ESTATE, "tz_net_broadcast: the root network has no weights");
     if (head[0] != 0) return TZ_OK;   // nothing to hand over
     blob.resize((size_t)head[1]);
     if ((rc = tz_comm_broadcast(c, blob.data(), blob.size(), root))) return rc;

@@ -96,8 +96,9 @@ __device__ __forceinline__ f32x4 mfma_f6(const i32x4& a0, const i32x2& a1, const
 }
 
 // One 3x3 conv over 256 input channels out of the image: for every tap and both K-halves G, the row tiles the tap does not skip.  A
-// step is a row tile's 6 RNX MFMAs into the one accumulator: wl x xh (FP6-scaled), the fp16 chunks 0..3, wh x xl (FP6-scaled) - the
-// same order in every workgroup form.  All of a (tap, G) group's weights are stationary together (4 RNX fp16 fragments, 2 RNX E2M3
+// step is a row tile's 6 RNX MFMAs into the one accumulator: wl x xh and wh x xl (FP6-scaled), then the fp16 chunks 0..3 - the same order
+// in every workgroup form; the two FP6 products sit together because every change of MFMA kind inside an accumulator's chain costs
+// issue time (measured: profiles/r03_c6_kloop_ab.txt).  All of a (tap, G) group's weights are stationary together (4 RNX fp16 fragments, 2 RNX E2M3
 // fragments, RNX scale dwords); the next group's replace them one by one as the group's last tile lets go of them.  A step reads the
 // next step's seven operands from LDS (4 fp16 fragments, the xl string in two pieces, the scale pair) while it computes - the reads
 // are pinned ahead of its MFMAs, left alone the scheduler sinks them to save registers - and converts the next step's xh copy
@@ -205,13 +206,35 @@ __device__ __forceinline__ void k_loop_c6(const unsigned char* lds, int lc0, f32
         __builtin_amdgcn_sched_barrier(0);
         const i32x4 xh0 = {(int)x6[slot][0], (int)x6[slot][1], (int)x6[slot][2], (int)x6[slot][3]};
         const i32x2 xh1 = {(int)x6[slot][4], (int)x6[slot][5]};
+#ifndef TZ_C6_ABL
+#define TZ_C6_ABL 0   // development builds: 1 = no (wl, xh) products and no conversion, 2 = no (wh, xl) products
+#endif
+        if constexpr (!(TZ_C6_ABL & 1)) {
 #pragma unroll
-        for (int j = 0; j < RNX; j++) acc[it.rt][j] = mfma_f6(W6a[0][j], W6b[0][j], xh0, xh1, acc[it.rt][j], Ws[j], sca[slot][0], false);
+            for (int j = 0; j < RNX; j++) acc[it.rt][j] = mfma_f6(W6a[0][j], W6b[0][j], xh0, xh1, acc[it.rt][j], Ws[j], sca[slot][0], false);
+        }
         if constexpr (last && more) {
 #pragma unroll
             for (int j = 0; j < RNX; j++) {
                 W6a[0][j] = w6a(ng.tap, ng.G, j, 0);
                 W6b[0][j] = w6b(ng.tap, ng.G, j, 0);
+            }
+        }
+        int wsn[RNX];
+        if constexpr (last && more) {   // the scale dwords of the next group: requested before this group's last use of its own
+#pragma unroll
+            for (int j = 0; j < RNX; j++) wsn[j] = wsf(ng.tap, ng.G, j);
+        }
+        if constexpr (!(TZ_C6_ABL & 2)) {
+#pragma unroll
+            for (int j = 0; j < RNX; j++) acc[it.rt][j] = mfma_f6(W6a[1][j], W6b[1][j], xa[slot], xb[slot], acc[it.rt][j], Ws[j], sca[slot][0], true);
+        }
+        if constexpr (last && more) {
+#pragma unroll
+            for (int j = 0; j < RNX; j++) {
+                W6a[1][j] = w6a(ng.tap, ng.G, j, 1);
+                W6b[1][j] = w6b(ng.tap, ng.G, j, 1);
+                Ws[j] = wsn[j];
             }
         }
 #pragma unroll
@@ -223,26 +246,11 @@ __device__ __forceinline__ void k_loop_c6(const unsigned char* lds, int lc0, f32
                 for (int j = 0; j < RNX; j++) Wf[c][j] = wf(ng.tap, 4 * ng.G + c, j);
             }
             if constexpr (more) {
-                if (c == 1) {
+                if (c == 1 && !(TZ_C6_ABL & 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     convert(slot ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-        }
-        int wsn[RNX];
-        if constexpr (last && more) {   // the scale dwords of the next group: requested before this group's last use of its own
-#pragma unroll
-            for (int j = 0; j < RNX; j++) wsn[j] = wsf(ng.tap, ng.G, j);
-        }
-#pragma unroll
-        for (int j = 0; j < RNX; j++) acc[it.rt][j] = mfma_f6(W6a[1][j], W6b[1][j], xa[slot], xb[slot], acc[it.rt][j], Ws[j], sca[slot][0], true);
-        if constexpr (last && more) {
-#pragma unroll
-            for (int j = 0; j < RNX; j++) {
-                W6a[1][j] = w6a(ng.tap, ng.G, j, 1);
-                W6b[1][j] = w6b(ng.tap, ng.G, j, 1);
-                Ws[j] = wsn[j];
             }
         }
     };

@@ -35,7 +35,8 @@ sp.close()
 c.close()
 # the id can also travel through a directory (what examples/selfplay_cli.cpp --comm rccl does)
 c2 = CM.Comm.rccl_from_directory(tmp_path, 0, 1, 0)
-assert os.path.getsize(os.path.join(tmp_path, "rccl_id.bin")) == CM.ID_BYTES and c2.all_gather(b"xy") == [b"xy"]
+# ... and is gone once the communicator is up: a later job in the same directory must not find this job's id (csrc/tz_comm.cpp)
+assert not os.path.exists(os.path.join(tmp_path, "rccl_id.bin")) and c2.all_gather(b"xy") == [b"xy"]
 c2.close()
 mcts.close()
 net.close()

@@ -265,6 +265,44 @@ def test_closed_loop_of_the_three_cpp_programs_over_ot_files(oracle, tmp_path):
     _check_lines(oracle, n, re_targets, None, "gumbel", game_values=False)
 
 
+def test_reanalyze_program_retries_a_torn_model_in_both_reload_modes(oracle, tmp_path):
+    """reanalyze retries every failed load on its next iteration (reanalyze/src/main.rs:93-105).  model_latest.ot is torn (the
+    reference's learn does not write it atomically) for the whole run: with and without --async-reload the program keeps the net
+    it has, says so at every iteration rather than once, and finishes its iterations."""
+    import subprocess
+
+    A = require_gpu()
+    from takzero_amd import ot
+    from takzero_amd import selfplay as SP
+    from takzero_amd import weights as W
+
+    exe = _build_example(tmp_path, "reanalyze_cli")
+    n = 4
+    mcts = A.BatchedMCTS(48, n, 4, agent_kind=A.AGENT_DUMMY, node_capacity=1 << 10)
+    sp = SP.NativeSelfPlay(mcts, 0, seed=3, shard=0, search="random", sampled_actions=64)
+    for _ in range(70):
+        sp.play_move()
+    replays = sp.take_text(1)
+    sp.close()
+    mcts.close()
+    for mode in ([], ["--async-reload"]):
+        d = str(tmp_path / ("run" + str(len(mode))))
+        os.makedirs(d)
+        open(os.path.join(d, "replays.txt"), "wb").write(replays)
+        W.save_tzw(os.path.join(d, "start.tzw"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=7))
+        ot.save_ot(os.path.join(d, "whole.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
+        whole = open(os.path.join(d, "whole.ot"), "rb").read()
+        open(os.path.join(d, "model_latest.ot"), "wb").write(whole[:len(whole) // 2])
+        r = subprocess.run([exe, "--directory", d, "--model", os.path.join(d, "start.tzw"), "--arch", "100", "--n", str(n), "--blocks", "1",
+                            "--games", "32", "--sims", "16", "--sampled-actions", "4", "--search", "gumbel", "--iterations", "6",
+                            "--min-positions", "100", "--wait-limit", "20", "--seed", "4"] + mode, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
+        f = _fields(r.stdout)
+        assert f["rc"] == "0" and f["model_reloads"] == "0", r.stdout
+        assert r.stderr.count("Cannot load model") >= 2, r.stderr[-1500:]
+        assert open(os.path.join(d, "targets-reanalyze.txt"), "rb").read().count(b"\n") == 6 * 32
+
+
 def test_evaluation_cpp_program_matches_models_up(oracle, tmp_path):
     """examples/evaluation_cli.cpp = the reference's `evaluation` binary (evaluation/src/main.rs:131-222) over the C ABI: picks
     two of the directory's model_<steps>.ot files (never model_latest.ot), loads them with load_partial semantics, starts the

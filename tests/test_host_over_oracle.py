@@ -75,7 +75,9 @@ def test_two_shards_exchange_packed_targets_like_one_directory(harness, tmp_path
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     fields = dict(zip(outs[0][0].split()[::2], outs[0][0].split()[1::2]))
     assert int(fields["collectives"]) == 3 * moves and int(fields["bytes"]) > 0
-    left = list(xdir.glob("xch-*"))                        # the transport cleans up after itself, bar the closing round's 8 bytes per rank
+    # the transport cleans up after itself, bar the closing round's 8 bytes per rank and the job's nonce (xch-job.bin, csrc/tz_comm.cpp)
+    left = [p for p in xdir.glob("xch-*") if p.name != "xch-job.bin"]
+    assert (xdir / "xch-job.bin").exists()
     assert len(left) == 2 and all(p.stat().st_size == 8 for p in left)
     for part in ("targets", "replays", "exploration"):
         got = [open("%s.%s" % (tmp_path / ("rank%d" % r), part), "rb").read().split(b"#move\n") for r in (0, 1)]
