@@ -392,6 +392,10 @@ int tz_trainer_step(tz_trainer* t, const tz_state* states, const float* target_p
                     float* losses_out);
 /* outputs of the last step's forward_t(xs, true): policy [batch][policy_size], value [batch], ube [batch] (log) */
 int tz_trainer_outputs(tz_trainer* t, float* policy_out, float* value_out, float* ube_out);
+/* what the last step's forward left after trunk layer `layer` (0 = input conv + BN + ReLU, then two per residual block, ReLU applied):
+ * [batch][n*n][256] floats, pixel-major (NHWC).  out_cap in floats.  For tests: where an activation is zero the step's backward took
+ * ReLU's derivative as zero — a comparison against another implementation can use the same side of the kink. */
+int tz_trainer_activation(tz_trainer* t, int layer, float* out, uint64_t out_cap);
 
 /* board size, batch and architecture of a trainer */
 int tz_trainer_shape(tz_trainer* t, int* board_n_out, int* batch_out, int* arch_out);

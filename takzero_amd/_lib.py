@@ -31,7 +31,7 @@ SYMBOLS = [
     "tz_search_step", "tz_search_restart_terminal", "tz_search_gumbel_sh", "tz_search_counters", "tz_search_sync", "tz_search_pool_usage",
     "tz_search_profile", "tz_device_math", "tz_debug_conv_bench", "tz_debug_tower_bench", "tz_net_load_prepare", "tz_net_load_commit", "tz_net_load_discard", "tz_debug_net_clock", "tz_debug_net_stamps", "tz_search_terminal_details", "tz_search_play_moves",
     "tz_trainer_create", "tz_trainer_destroy", "tz_trainer_tensor_count", "tz_trainer_tensor_info",
-    "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs",
+    "tz_trainer_set_tensor", "tz_trainer_get_tensor", "tz_trainer_step", "tz_trainer_outputs", "tz_trainer_activation",
     "tz_format_targets", "tz_parse_targets", "tz_search_improved_policy_each", "tz_search_shape",
     "tz_selfplay_create", "tz_selfplay_destroy", "tz_selfplay_play_move", "tz_selfplay_counters", "tz_selfplay_take_text",
     "tz_selfplay_run", "tz_reanalyze_create", "tz_reanalyze_destroy", "tz_reanalyze_feed", "tz_reanalyze_iterate",
@@ -177,6 +177,7 @@ def load():
     lib.tz_trainer_get_tensor.argtypes = [vp, C.c_char_p, ci, vp, C.c_uint64]
     lib.tz_trainer_step.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, vp]
     lib.tz_trainer_outputs.argtypes = [vp, vp, vp, vp]
+    lib.tz_trainer_activation.argtypes = [vp, ci, vp, C.c_uint64]
     _lib = lib
     return lib
 

@@ -11,7 +11,10 @@
 //   backward      dW = im2col(x)^T x dc  (A-transposed GEMM);  dx = im2col(dc) x W'  with W' = taps mirrored, ci/co swapped
 //   parameters, gradients and the two Adam moments live in four parallel arenas; one Adam launch per step.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <map>
 #include <string>
@@ -102,35 +105,35 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
     // operands of k-steps i and i + 1 are in flight while step i - 1 multiplies: one step (a thousand cycles) does not cover a
     // miss of the XCD's L2 on the gathered view, two do
-    float4 ra[2], rb[2];
-    auto fetch = [&](int slot) {
-        ra[slot] = GATHER ? gather() : *(const float4*)ap;
-        rb[slot] = *(const float4*)bp;
+    float4 ra0, ra1, rb0, rb1;   // named, not an array: a slot picked at run time would send them to scratch
+    auto fetch = [&](float4& ra, float4& rb) {
+        ra = GATHER ? gather() : *(const float4*)ap;
+        rb = *(const float4*)bp;
     };
     auto advance = [&]() {
         bp += bstep;
         if (GATHER) gather_advance();
         else ap += astep;
     };
-    fetch(0);
+    fetch(ra0, rb0);
     if (32 < K) {
         advance();
-        fetch(1);
+        fetch(ra1, rb1);
     }
-    auto step = [&](int k0, int buf, int slot) {
+    auto step = [&](int k0, int buf, float4& ra, float4& rb) {
         if (AT) {
-            *(float4*)&As[buf][g][ak][am] = ra[slot];
+            *(float4*)&As[buf][g][ak][am] = ra;
         } else {
-            As[buf][g][ak + 0][am] = ra[slot].x;
-            As[buf][g][ak + 1][am] = ra[slot].y;
-            As[buf][g][ak + 2][am] = ra[slot].z;
-            As[buf][g][ak + 3][am] = ra[slot].w;
+            As[buf][g][ak + 0][am] = ra.x;
+            As[buf][g][ak + 1][am] = ra.y;
+            As[buf][g][ak + 2][am] = ra.z;
+            As[buf][g][ak + 3][am] = ra.w;
         }
-        *(float4*)&Bs[buf][g][bk][bn] = rb[slot];
+        *(float4*)&Bs[buf][g][bk][bn] = rb;
         __syncthreads();
         if (k0 + 64 < K) {
             advance();
-            fetch(slot);
+            fetch(ra, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
         }
     };
     for (int k0 = 0; k0 < K; k0 += 64) {
-        step(k0, 0, 0);
-        if (k0 + 32 < K) step(k0 + 32, 1, 1);
+        step(k0, 0, ra0, rb0);
+        if (k0 + 32 < K) step(k0 + 32, 1, ra1, rb1);
     }
     __syncthreads();
     float* red = &As[0][0][0][0];  // 64 x 64 partial tile of group 1
@@ -160,6 +163,223 @@ __global__ __launch_bounds__(512) void gemm_f32_kernel(const float* __restrict__
         float v = acc[r] + red[ml * 64 + wn + (lane & 31)] + bv;
         if (accumulate) v += C[m * ldc + n];
         C[m * ldc + n] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product, its work cut so that every CU gets an equal share ("stream-K").  At the reference's batch of 128 a forward or
+// data-gradient GEMM is 200 tiles of 64x64 and a weight-gradient GEMM 144 — for 256 CUs.  Here the (tile, k-slab) pairs are laid
+// out in one line, tile by tile, and workgroup w of G takes the contiguous range [w T / G, (w + 1) T / G): it walks through at most
+// one partial tile, whole tiles, one partial tile.  A whole tile gets the usual epilogue; a partial one goes to the workgroup's
+// slot in a workspace, and gemm_fixup_kernel adds a tile's parts in ascending k (ascending workgroup) — a fixed order, so the
+// result does not depend on timing.  A workgroup is 4 waves, one 32x32 quadrant each over the full slab depth of 32: two of them
+// share a CU (G = 2 x CUs), each with its own barriers, so one's barrier wait is the other's MFMA time.
+struct SkRange {
+    long long begin, end;
+};
+__device__ __host__ inline SkRange sk_range(int w, int G, long long total) {
+    return SkRange{(long long)w * total / G, (long long)(w + 1) * total / G};
+}
+
+template <bool AT, bool GATHER>
+__global__ __launch_bounds__(256) void gemm_sk_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                      const float* __restrict__ bias, int K, int lda, int ldb, int ldc, int accumulate,
+                                                      int gn, int gc, int tiles_m, long long total, float* __restrict__ ws) {
+    __shared__ float As[2][32][68];  // [buffer][k][m]
+    __shared__ float Bs[2][32][68];
+    __shared__ int srcoff[9][40];    // [tap][pixel in board] -> (source pixel in board) * gc, or -1 (see gemm_f32_kernel)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int S = K / 32, gnn = gn * gn;
+    const SkRange mine = sk_range(blockIdx.x, gridDim.x, total);
+    if (GATHER) {
+        for (int i = t; i < 9 * gnn; i += 256) {
+            const int tap = i / gnn, lp = i - tap * gnn, y = lp / gn + tap / 3 - 1, x = lp % gn + tap % 3 - 1;
+            srcoff[tap][lp] = (y >= 0 && y < gn && x >= 0 && x < gn) ? (y * gn + x) * gc : -1;
+        }
+        __syncthreads();
+    }
+    // loader: two float4 per thread and operand per slab.  !AT: 4 consecutive k of rows am, am + 32;  AT: 4 consecutive m of k-rows ak, ak + 16
+    const int ak = AT ? (t >> 4) : (t & 7) * 4, am = AT ? (t & 15) * 4 : (t >> 3);
+    const int bk = t >> 4, bn = (t & 15) * 4;
+    for (long long cur = mine.begin; cur < mine.end;) {
+        const int tile = (int)(cur / S), ks0 = (int)(cur - (long long)tile * S);
+        const int ks1 = (int)((long long)S < ks0 + (mine.end - cur) ? (long long)S : ks0 + (mine.end - cur));
+        const size_t m0 = (size_t)(tile % tiles_m) * 64, n0 = (size_t)(tile / tiles_m) * 64;
+        // state of the thread's two fetches per slab (h = 0, 1): plain pointer, or board / pixel inside the board / tap / channel of the
+        // gathered view.  Named objects throughout: an array indexed by h would live in scratch.
+        struct Src {
+            const float* ap;
+            const float* row;
+            int lp, tap, c;
+        };
+        auto src_init = [&](int h) -> Src {
+            Src q{A, A, 0, 0, 0};
+            if (GATHER) {
+                const int pix = AT ? 32 * ks0 + ak + 16 * h : (int)m0 + am + 32 * h, k = AT ? (int)m0 + am : 32 * ks0 + ak;
+                const int b = pix / gnn;
+                q.lp = pix - b * gnn;
+                q.row = A + (size_t)b * gnn * gc;
+                q.tap = k / gc;            // >= 9 marks the K padding
+                q.c = k - q.tap * gc;
+            } else {
+                q.ap = AT ? A + (size_t)(32 * ks0 + ak + 16 * h) * lda + m0 + am : A + (m0 + am + 32 * h) * lda + 32 * ks0 + ak;
+            }
+            return q;
+        };
+        Src s0 = src_init(0), s1 = src_init(1);
+        const float* bp = B + (size_t)(32 * ks0 + bk) * ldb + n0 + bn;
+        const size_t astep = AT ? (size_t)32 * lda : 32, bstep = (size_t)32 * ldb, bhalf = (size_t)16 * ldb;
+        auto load_a = [&](const Src& q) -> float4 {
+            if (GATHER) {
+                const int off = q.tap < 9 ? srcoff[q.tap][q.lp] : -1;
+                return off < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(q.row + off + q.c);
+            }
+            return *(const float4*)q.ap;
+        };
+        auto advance_a = [&](Src& q) {
+            if (!GATHER) {
+                q.ap += astep;
+            } else if (AT) {
+                q.lp += 32;
+                while (q.lp >= gnn) {
+                    q.lp -= gnn;
+                    q.row += gnn * gc;
+                }
+            } else {
+                q.c += 32;
+                while (q.c >= gc) {
+                    q.c -= gc;
+                    q.tap++;
+                }
+            }
+        };
+        struct Slab {
+            float4 a0, a1, b0, b1;
+        };
+        auto fetch = [&](Slab& f) {
+            f.a0 = load_a(s0);
+            f.a1 = load_a(s1);
+            f.b0 = *(const float4*)bp;
+            f.b1 = *(const float4*)(bp + bhalf);
+        };
+        auto advance = [&]() {
+            bp += bstep;
+            advance_a(s0);
+            advance_a(s1);
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
+        Slab f0, f1;   // slabs i and i + 1 in flight while slab i - 1 multiplies
+        fetch(f0);
+        if (ks0 + 1 < ks1) {
+            advance();
+            fetch(f1);
+        }
+        auto store_a = [&](int buf, int h, const float4& v) {
+            if (AT) {
+                *(float4*)&As[buf][ak + 16 * h][am] = v;
+            } else {
+                As[buf][ak + 0][am + 32 * h] = v.x;
+                As[buf][ak + 1][am + 32 * h] = v.y;
+                As[buf][ak + 2][am + 32 * h] = v.z;
+                As[buf][ak + 3][am + 32 * h] = v.w;
+            }
+        };
+        auto step = [&](int ks, int buf, Slab& f) {
+            store_a(buf, 0, f.a0);
+            store_a(buf, 1, f.a1);
+            *(float4*)&Bs[buf][bk][bn] = f.b0;
+            *(float4*)&Bs[buf][bk + 16][bn] = f.b1;
+            __syncthreads();
+            if (ks + 2 < ks1) {
+                advance();
+                fetch(f);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 32; kk += 2) {
+                const float a = As[buf][kk + (lane >> 5)][wm + (lane & 31)];
+                const float b = Bs[buf][kk + (lane >> 5)][wn + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        };
+        for (int ks = ks0; ks < ks1; ks += 2) {
+            step(ks, 0, f0);
+            if (ks + 1 < ks1) step(ks + 1, 1, f1);
+        }
+        __syncthreads();   // the next segment's first store goes to buffer 0
+        const bool whole = ks0 == 0 && ks1 == S;
+        if (whole) {
+            const size_t n = n0 + wn + (lane & 31);
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const size_t m = m0 + wm + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                float v = acc[r] + bv;
+                if (accumulate) v += C[m * ldc + n];
+                C[m * ldc + n] = v;
+            }
+        } else {   // slot 0: the range's first segment, slot 1: its last
+            float* part = ws + ((size_t)blockIdx.x * 2 + (cur == mine.begin ? 0 : 1)) * 4096;
+#pragma unroll
+            for (int r = 0; r < 16; r++) part[(wm + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 64 + wn + (lane & 31)] = acc[r];
+        }
+        cur += ks1 - ks0;
+    }
+}
+
+// One workgroup per tile: nothing to do for a tile that one workgroup multiplied whole; otherwise the parts, in ascending k.
+// (32-bit range arithmetic: w * total < 2^32 for every launch — 64-bit divisions would be most of this kernel's time.)
+__device__ inline unsigned sk_begin32(unsigned w, unsigned G, unsigned total) { return w * total / G; }
+
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(float* __restrict__ C, const float* __restrict__ bias, int S, int ldc, int accumulate,
+                                                         int tiles_m, unsigned total, unsigned G, const float* __restrict__ ws) {
+    const unsigned tile = blockIdx.x;
+    const unsigned t0 = tile * (unsigned)S, t1 = t0 + (unsigned)S;
+    unsigned w = t0 * G / total;
+    while (w > 0 && sk_begin32(w, G, total) > t0) w--;
+    while (sk_begin32(w + 1, G, total) <= t0) w++;
+    if (sk_begin32(w, G, total) <= t0 && sk_begin32(w + 1, G, total) >= t1) return;
+    const size_t m0 = (size_t)(tile % tiles_m) * 64, n0 = (size_t)(tile / tiles_m) * 64;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; w < G; w++) {
+        const unsigned begin = sk_begin32(w, G, total);
+        if (begin >= t1) break;
+        // its first segment unless the range began in an earlier tile
+        const float4* part = reinterpret_cast<const float4*>(ws + ((size_t)w * 2 + (begin >= t0 ? 0 : 1)) * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 p = part[i * 256 + threadIdx.x];
+            v[i].x += p.x;
+            v[i].y += p.y;
+            v[i].z += p.z;
+            v[i].w += p.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = (i * 256 + threadIdx.x) * 4;
+        const size_t m = m0 + (e >> 6), n = n0 + (e & 63);
+        float4 x = v[i];
+        if (bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+            x.x += bv.x;
+            x.y += bv.y;
+            x.z += bv.z;
+            x.w += bv.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+        if (accumulate) {
+            const float4 c = *dst;
+            x.x += c.x;
+            x.y += c.y;
+            x.z += c.z;
+            x.w += c.w;
+        }
+        *dst = x;
     }
 }
 
@@ -553,6 +773,9 @@ struct tz_trainer {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_dc[2] = {nullptr, nullptr}, ev_w[2] = {nullptr, nullptr};
     float* dC2 = nullptr;
+    // stream-K GEMMs: workgroups per launch (two per CU) and, per stream, two 64x64 slots per workgroup for partial tiles
+    int sk_groups = 512;
+    float* sk_ws[2] = {nullptr, nullptr};
     std::vector<void*> allocs;
     TensorStore extra;   // variables of the VarStore the step never touches (RND nets, SimHash matrix): carried through save / load
 };
@@ -617,10 +840,29 @@ int launch_check(const char* what) {
 int gemm(tz_trainer* t, bool at, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
          int ldb, int ldc, bool accumulate, hipStream_t st = nullptr, int gather_c = 0) {
     if (!st) st = t->stream;
-    if (M % 64 || N % 64 || K % 32 || lda % 4 || ldb % 4 || gather_c % 4)
+    if (M % 64 || N % 64 || K % 32 || lda % 4 || ldb % 4 || ldc % 4 || gather_c % 4 || (long long)(M / 64) * (N / 64) * (K / 32) > (1ll << 22))
         return tz_fail(TZ_EINVAL, "trainer gemm: unaligned shape");
-    const dim3 grid(M / 64, N / 64);
     const int acc = accumulate ? 1 : 0;
+    static const bool tiled = getenv("TZ_LEARN_GEMM") && !strcmp(getenv("TZ_LEARN_GEMM"), "tile");   // A/B: one workgroup per tile
+    if (!tiled) {
+        const int tiles_m = M / 64, tiles = tiles_m * (N / 64), S = K / 32;
+        const long long total = (long long)tiles * S;
+        const int G = (int)std::min<long long>(total, t->sk_groups);
+        float* ws = st == t->stream2 ? t->sk_ws[1] : t->sk_ws[0];
+        const int gn = gather_c ? t->n : 0;
+        if (gather_c && at)
+            gemm_sk_kernel<true, true><<<G, 256, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, gn, gather_c, tiles_m, total, ws);
+        else if (gather_c)
+            gemm_sk_kernel<false, true><<<G, 256, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, gn, gather_c, tiles_m, total, ws);
+        else if (at)
+            gemm_sk_kernel<true, false><<<G, 256, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, 0, 0, tiles_m, total, ws);
+        else
+            gemm_sk_kernel<false, false><<<G, 256, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, 0, 0, tiles_m, total, ws);
+        if (total % G || (total / G) % S)   // some tile is shared between workgroups
+            gemm_fixup_kernel<<<tiles, 256, 0, st>>>(C, bias, S, ldc, acc, tiles_m, (unsigned)total, (unsigned)G, ws);
+        return launch_check("gemm_sk");
+    }
+    const dim3 grid(M / 64, N / 64);
     if (gather_c) {   // A = im2col view of the NHWC tensor at `A` with gather_c channels
         if (at)
             gemm_f32_kernel<true, true><<<grid, 512, 0, st>>>(A, B, C, bias, K, lda, ldb, ldc, acc, t->n, gather_c);
@@ -847,6 +1089,12 @@ int tz_trainer_create(int board_n, int arch, int device_id, int blocks, int batc
         if ((rc = dalloc(t, &t->dB, act))) break;
         if ((rc = dalloc(t, &t->dC, act))) break;
         if ((rc = dalloc(t, &t->dC2, act))) break;
+        {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->sk_groups = 2 * cus;
+            if ((rc = dalloc(t, &t->sk_ws[0], (size_t)t->sk_groups * 2 * 4096))) break;
+            if ((rc = dalloc(t, &t->sk_ws[1], (size_t)t->sk_groups * 2 * 4096))) break;
+        }
         if ((rc = dalloc(t, &t->dskip, act))) break;
         if ((rc = dalloc(t, &t->pol, (size_t)t->M * t->np))) break;
         if ((rc = dalloc(t, &t->dpol, (size_t)t->M * t->np))) break;
@@ -1100,6 +1348,17 @@ int tz_trainer_outputs(tz_trainer* t, float* policy_out, float* value_out, float
     }
     if (value_out) TZ_HIP(hipMemcpy(value_out, t->value, sizeof(float) * t->batch, hipMemcpyDeviceToHost));
     if (ube_out) TZ_HIP(hipMemcpy(ube_out, t->ube, sizeof(float) * t->batch, hipMemcpyDeviceToHost));
+    return TZ_OK;
+}
+
+int tz_trainer_activation(tz_trainer* t, int layer, float* out, uint64_t cap) {
+    if (!t || !out) return tz_fail(TZ_EINVAL, "tz_trainer_activation: null argument");
+    if (layer < 0 || layer >= t->layers) return tz_fail(TZ_EINVAL, "tz_trainer_activation: no such trunk layer");
+    const size_t real = (size_t)t->batch * t->nn * FILTERS;
+    if (cap < real) return tz_fail(TZ_EINVAL, "tz_trainer_activation: the buffer holds fewer than batch * n * n * 256 values");
+    TZ_HIP(hipSetDevice(t->device));
+    TZ_HIP(hipStreamSynchronize(t->stream));
+    TZ_HIP(hipMemcpy(out, t->a[layer], real * sizeof(float), hipMemcpyDeviceToHost));
     return TZ_OK;
 }
 

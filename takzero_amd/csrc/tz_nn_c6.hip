@@ -587,6 +587,9 @@ __global__ __launch_bounds__(512, 2) void net_c6_kernel(NetArgs a) {
                 const int rec = layer * LAYER_REC6 + (tap * 2 + G) * 16 + (ct0 + j);
                 return __builtin_amdgcn_raw_buffer_load_b32(wrsrc6, opaque(lane16) >> 2, rec * REC6 + 3072, 0);
             };
+#ifdef TZ_C6_SKEW   // development builds: the second wave of every SIMD starts its k-loop 64 x TZ_C6_SKEW cycles late
+            if (wave >= 4) __builtin_amdgcn_s_sleep(TZ_C6_SKEW);
+#endif
             k_loop_c6<NB, P, PERM, RN>(lds, lane_const, acc, tab, wl, w6a, w6b, wsf);
         }
         __syncthreads();

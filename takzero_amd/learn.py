@@ -132,6 +132,12 @@ class Trainer:
         check(self.lib.tz_trainer_outputs(self.h, pol.ctypes.data, val.ctypes.data, ube.ctypes.data))
         return pol, val, ube
 
+    def activation(self, layer):
+        """Output of trunk layer `layer` in the last step's forward, [batch, n*n, 256] (tz_trainer_activation)."""
+        out = np.zeros((self.batch, self.n * self.n, 256), np.float32)
+        check(self.lib.tz_trainer_activation(self.h, layer, out.ctypes.data, out.size))
+        return out
+
 
 # ---------------------------------------------------------------------------------------------
 # learn::main (learn/src/main.rs:99-289): replay buffers with forced uses, back-pressure file, model files

@@ -54,8 +54,12 @@ def test_step_matches_torch_autograd(n, blocks):
         grads = {k: tr.tensor(k, L.GRAD) for k in tr.names if "running_" not in k}
         outs = tr.outputs()
         opt.zero_grad(set_to_none=True)
+        # A ReLU input within rounding of zero has no derivative to compare: its mask is whatever side the last fp32 rounding fell on,
+        # and one flipped pixel moves a conv's weight gradient by a percent (seen: layer 2, one input at 1.8e-7 against 0.0 under
+        # another summation order of the same GEMM).  At those entries the reference takes the side the trainer took.
+        relu_masks = [torch.from_numpy(tr.activation(l).transpose(0, 2, 1).reshape(B, 256, n, n) > 0) for l in range(1 + 2 * blocks)]
         want, wouts = LT.losses(p, torch.from_numpy(planes), torch.from_numpy(mask.astype(bool)), torch.from_numpy(policy),
-                                torch.from_numpy(value), torch.from_numpy(ube), blocks, train_ube)
+                                torch.from_numpy(value), torch.from_numpy(ube), blocks, train_ube, relu_masks=relu_masks)
         (want[0] + want[1] + want[2]).backward()
         # identical weights on both sides (see the re-synchronisation below), only the fp32 summation order differs
         # (measured: 2e-6 on the outputs, 2e-6 relative on the gradients)

@@ -272,6 +272,7 @@ def test_reanalyze_program_retries_a_torn_model_in_both_reload_modes(oracle, tmp
     import subprocess
 
     A = require_gpu()
+    from takzero_amd import formats as F
     from takzero_amd import ot
     from takzero_amd import selfplay as SP
     from takzero_amd import weights as W
@@ -289,6 +290,7 @@ def test_reanalyze_program_retries_a_torn_model_in_both_reload_modes(oracle, tmp
         d = str(tmp_path / ("run" + str(len(mode))))
         os.makedirs(d)
         open(os.path.join(d, "replays.txt"), "wb").write(replays)
+        open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(0, 0))
         W.save_tzw(os.path.join(d, "start.tzw"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=7))
         ot.save_ot(os.path.join(d, "whole.ot"), W.init_weights(W.ARCH_TEST, n=n, blocks=1, seed=8))
         whole = open(os.path.join(d, "whole.ot"), "rb").read()
