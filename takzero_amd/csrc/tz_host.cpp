@@ -668,6 +668,11 @@ int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_b
     };
     int rc = TZ_OK;
     for (int step = 0; moves < 0 || step < moves; step++) {
+        // What this rank found before the move: its own reasons to stop.  With N shards nobody leaves on its own — a rank that
+        // walked out here would strand the others in the move's all-gather for good (RCCL has no timeout) — so the ranks first
+        // exchange one status word and stop together, every collective of the round matched.
+        int local = TZ_OK;
+        std::string local_msg;
         double waited = 0.0;
         for (;;) {  // the inner `loop` of selfplay::main
             long a = -1, b = -1, c = -1;
@@ -676,13 +681,36 @@ int tz_selfplay_run(tz_selfplay* sp, const char* directory, int moves, int max_b
             if (f) fclose(f);
             if (ok && a <= max_buffer_len) break;
             if (wait_limit_s >= 0 && waited >= wait_limit_s) {
-                finish();
-                return tz_fail(TZ_ESTATE, ok ? "tz_selfplay_run: learn's buffer stayed over its cap" : "tz_selfplay_run: buffer_lengths.txt unreadable");
+                local = TZ_ESTATE;
+                local_msg = ok ? "tz_selfplay_run: learn's buffer stayed over its cap" : "tz_selfplay_run: buffer_lengths.txt unreadable";
+                break;
             }
             std::this_thread::sleep_for(std::chrono::milliseconds(wait_limit_s >= 0 && wait_limit_s < 1 ? 10 : 1000));
             waited += wait_limit_s >= 0 && wait_limit_s < 1 ? 0.01 : 1.0;
         }
-        if (reload && (rc = reload(reload_user))) break;
+        if (reload) {   // called on every rank even when this one is about to stop: the callback may hold a collective (tz_net_broadcast)
+            const int r = reload(reload_user);
+            if (r && !local) {
+                local = r;
+                local_msg = tz_last_error();
+            }
+        }
+        if (sp->has_exchange && sp->xch.world > 1) {
+            std::vector<unsigned char> mine(sizeof(int32_t));
+            const int32_t word = local;
+            memcpy(mine.data(), &word, sizeof word);
+            std::vector<std::vector<unsigned char>> all;
+            if ((rc = sp->xch.all_gather(mine, all))) break;
+            for (size_t r = 0; r < all.size() && !rc; r++) {
+                int32_t theirs = 0;
+                if (all[r].size() == sizeof theirs) memcpy(&theirs, all[r].data(), sizeof theirs);
+                if (theirs) rc = local ? tz_fail(local, local_msg) : tz_fail(theirs, "tz_selfplay_run: rank " + std::to_string(r) + " stopped before the move");
+            }
+            if (rc) break;
+        } else if (local) {
+            rc = tz_fail(local, local_msg);
+            break;
+        }
         if ((rc = tz_selfplay_play_move(sp))) break;
         if ((rc = tz_selfplay_exchange(sp))) break;   // N shards: the writer rank appends everybody's lines
         if (sp->has_exchange && sp->xch.writer < 0 && sp->xch.rank != 0) {   // every rank holds them: one copy goes to the files

@@ -439,6 +439,31 @@ def test_two_shards_through_the_rccl_side_of_the_communicator(oracle, tmp_path):
     assert open(os.path.join(d2, "replays.txt"), "rb").read() == replays
 
 
+def test_a_shard_that_has_to_stop_takes_the_others_with_it(tmp_path):
+    """tz_selfplay_run with N shards: before every move the ranks exchange one status word, so a rank whose own look at the
+    directory says stop (here: learn's buffer over its cap for longer than --wait-limit, seen by rank 1 only) does not walk out of
+    the move's all-gather and leave rank 0 waiting in it for good: both processes end, each with an error that says who stopped."""
+    import subprocess
+
+    require_gpu()
+    from takzero_amd import formats as F
+
+    exe = _build_example(tmp_path, "selfplay_cli")
+    dirs = [str(tmp_path / "run0"), str(tmp_path / "run1")]
+    os.makedirs(tmp_path / "xch")
+    for d, lengths in zip(dirs, ((0, 0), (40000, 0))):
+        os.makedirs(d)
+        open(os.path.join(d, "buffer_lengths.txt"), "w").write(F.format_buffer_lengths(*lengths))
+    procs = [subprocess.Popen([exe, "--directory", dirs[rk], "--arch", "100", "--n", "4", "--blocks", "1", "--games", "32", "--sims", "16",
+                               "--sampled-actions", "4", "--search", "gumbel", "--moves", "400", "--wait-limit", "2", "--seed", "3",
+                               "--rank", str(rk), "--world", "2", "--comm", "fs", "--comm-dir", str(tmp_path / "xch"), "--device", "0"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for rk in (0, 1)]
+    outs = [p.communicate(timeout=300) for p in procs]          # a stranded rank would sit here until the timeout
+    assert all(p.returncode != 0 for p in procs), [o[0][-300:] for o in outs]
+    assert "rank 1 stopped before the move" in outs[0][1], outs[0][1][-800:]
+    assert "buffer stayed over its cap" in outs[1][1], outs[1][1][-800:]
+
+
 @pytest.mark.parametrize("kind,sims,k,exploration,agent,n", [(0, 24, 64, 1, 2, 4), (1, 16, 4, 0, 2, 4), (1, 48, 8, 1, 1, 5), (2, 0, 64, 0, 1, 4)])
 def test_native_drivers_write_the_same_bytes_over_the_gpu_engine_and_over_the_oracle(tmp_path, kind, sims, k, exploration, agent, n):
     """The strongest statement about the whole loop: csrc/tz_host.cpp driving the HIP engine and the very same driver
