@@ -4049,8 +4049,41 @@ int tz_net_broadcast(tz_net* net, tz_comm* c, int root, int status) {
     if (head[0] != 0) return TZ_OK;   // nothing to hand over
     blob.resize((size_t)head[1]);
     if ((rc = tz_comm_broadcast(c, blob.data(), blob.size(), root))) return rc;
+    // SimHash nets: the root's load also replaced its set of seen hashes (bitvec.bin beside the model, net6_simhash.rs:173-190), so
+    // the set travels with the variables — 2^32 bits in 64 MiB pieces through a host buffer.  Every rank runs every round, whatever
+    // happens to its own copies: an error is reported after the last collective.
+    int set_rc = TZ_OK;
+    uint32_t* staging = nullptr;
+    if (net->has_hash && world > 1) {
+        const size_t total = (size_t)1 << 29, chunk = (size_t)1 << 26;
+        std::vector<unsigned char> buf(chunk);
+        if (hipSetDevice(net->device) != hipSuccess) set_rc = TZ_EDEVICE;
+        if (!set_rc && rank == root && hipStreamSynchronize(net->stream) != hipSuccess) set_rc = TZ_EDEVICE;
+        if (!set_rc && rank != root && hipMalloc(&staging, total) != hipSuccess) set_rc = TZ_ENOMEM;
+        for (size_t done = 0; done < total; done += chunk) {
+            if (rank == root && !set_rc && hipMemcpy(buf.data(), (unsigned char*)net->bitset + done, chunk, hipMemcpyDeviceToHost) != hipSuccess)
+                set_rc = TZ_EDEVICE;
+            if ((rc = tz_comm_broadcast(c, buf.data(), chunk, root))) break;
+            if (rank != root && !set_rc && hipMemcpy((unsigned char*)staging + done, buf.data(), chunk, hipMemcpyHostToDevice) != hipSuccess)
+                set_rc = TZ_EDEVICE;
+        }
+        if (rc || set_rc) {
+            if (staging) (void)hipFree(staging);
+            return rc ? rc : tz_fail(set_rc, "tz_net_broadcast: the set of seen hashes could not be handed over");
+        }
+    }
     if (rank == root) return TZ_OK;
-    return tz_net_load_weights_mem(net, blob.data(), blob.size());
+    rc = tz_net_load_weights_mem(net, blob.data(), blob.size());
+    if (staging) {
+        if (rc) {   // the old model stays, and so does its set
+            (void)hipFree(staging);
+            return rc;
+        }
+        TZ_HIP(hipStreamSynchronize(net->stream));
+        (void)hipFree(net->bitset);
+        net->bitset = staging;
+    }
+    return rc;
 }
 
 int tz_weights_convert(const char* src, const char* dst) {
