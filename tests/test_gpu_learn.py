@@ -315,3 +315,27 @@ def test_native_learn_main_loop_on_a_directory(tmp_path):
     with pytest.raises(Stop):   # an exception in the step callback ends the native loop and surfaces here
         loop.run(d, steps, 50, min_selfplay=B, steps_before_reanalyze=10 ** 9, read_interval=0.0, sleep=0.01, max_wait=10, on_step=raising)
     loop.close()
+
+
+def test_stream_k_gemm_equals_the_tile_gemm_on_every_shape_of_a_step(tmp_path):
+    """csrc/tz_learn.hip: gemm_sk_kernel + gemm_fixup_kernel (equal shares of (tile, k-slab) pairs per workgroup, parts added in
+    ascending k) against gemm_f32_kernel (one workgroup per tile) on the same operands — plain / transposed A, stored / gathered
+    im2col view, with and without bias and accumulation, at the shapes of a batch-128 and a batch-64 step on 5x5, a 6x6 shape,
+    and with 512, 96 and 7 workgroups (1 to hundreds of slabs each); the workspace starts as NaN, so a part that is read without
+    having been written shows.  tools/learn_gemm_check.hip includes the unit itself (the kernels are in an anonymous namespace)."""
+    import subprocess
+
+    require_gpu()
+    from takzero_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "learn_gemm_check")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w",
+                        "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "learn_gemm_check.hip"),
+                        "-L" + os.path.dirname(_lib.LIB_PATH), "-ltakzero_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-ldl", "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot build the check here: " + r.stderr[-300:])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all equal to rounding" in r.stdout and "MISMATCH" not in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+    assert r.stdout.count("max |diff|") == 45
