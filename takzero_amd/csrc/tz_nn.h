@@ -46,6 +46,13 @@ struct tz_net {
     void *rnd_in = nullptr, *rnd_h1 = nullptr, *rnd_h2 = nullptr;  // RND activations
     float* rnd_out = nullptr;                                       // [2][max_batch][512]
     void* seeds = nullptr;     // TZ_PREC_F16C6: the blocks' inputs (fp32) between the two convs of a block (tz_nn_c6.hip)
+    // tz_net_eval at small batches: several CUs per board group (net_mfma_kernel SPLIT): the groups' exchange buffer and arrival
+    // counters, allocated at the first such call; `eval_split` is set for the duration of a tz_net_eval call only
+    void* xch = nullptr;
+    unsigned* xch_count = nullptr;
+    bool eval_split = false;
+    hipStream_t stream_rnd = nullptr;   // ... and the stream the RND MLP runs on beside the net kernel in such a call
+    hipEvent_t ev_in = nullptr, ev_rnd = nullptr;
     hipStream_t stream = nullptr;
     void* dbg_buf = nullptr;   // diagnostic builds: in-kernel stamps of the last launch (tz_debug_net_clock)
     int dbg_groups = 0;

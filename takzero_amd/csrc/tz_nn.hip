@@ -943,6 +943,10 @@ struct NetArgs {
     unsigned long long* dbg;   // diagnostic builds (ABL & 8): [workgroup][4] = memtime, memrealtime before / after the tower
     // TZ_PREC_F16C6 (tz_nn_c6.hip): w8 / w_pol8 hold its E2M3 records; a block's input (fp32) waits here for the block's second conv
     void* seeds;
+    // SPLIT > 1 (several CUs per board group, small batches through tz_net_eval): the groups' exchange buffer [group][2][8 planes] and
+    // their arrival counters (one 128-byte line each, zeroed before the launch)
+    unsigned char* xch;
+    unsigned* xch_count;
 };
 
 // 72 k-steps of one 256-input-channel 3x3 conv out of the LDS image: activation fragments one k-step ahead,
@@ -953,16 +957,19 @@ struct NetArgs {
 // PD = weight prefetch distance in k-steps: 2 (ring of 4) for the full-size workgroups, whose k-steps are 26 MFMAs long;
 // 6 (ring of 8) for the 1- and 2-board workgroups of small batches, whose k-steps are 4-8 MFMAs and which would
 // otherwise wait for L2 at every step.
+// `pre` (optional): the first PD weight fragments per column tile, [d][j], already requested by the caller (the several-CU form asks
+// for the next layer's before it waits for its partners)
 template <int NB, int RT, int RNX, int ROWS, int ZROW, int PLANE, typename ET, int PD = 2, typename WL>
-__device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&acc)[RT][RNX], WL wl) {
+__device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&acc)[RT][RNX], WL wl,
+                                           const typename Elem<ET>::x8* pre = nullptr) {
     typedef typename Elem<ET>::x8 ex8;
-    constexpr int TAPS = 9, RING = PD <= 2 ? 4 : 8;
-    static_assert(PD < RING && PD <= 8, "prefetch distance");
+    constexpr int TAPS = 9, RING = PD <= 2 ? 4 : PD <= 6 ? 8 : 16;
+    static_assert(PD < RING && PD <= 14, "prefetch distance");
     ex8 bq[RING][RNX];
 #pragma unroll
     for (int j = 0; j < RNX; j++) {
 #pragma unroll
-        for (int d = 0; d < PD; d++) bq[d][j] = wl(0, d, j);
+        for (int d = 0; d < PD; d++) bq[d][j] = pre ? pre[d * RNX + j] : wl(d / 8, d % 8, j);
     }
     int abase[RT];
 #pragma unroll
@@ -970,15 +977,18 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* 
     ex8 av[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
+    // a ring of 16 (the several-CU form: 12 fragments in flight per wave, which is what its weight stream lives on) has its slot
+    // depend on the tap: the tap loop is unrolled with it so that every slot is a register picked at compile time
+#pragma unroll(RING > 8 ? TAPS : 1)
     for (int tap = 0; tap < TAPS; tap++) {
 #pragma unroll
         for (int kc = 0; kc < 8; kc++) {
-            if (kc + PD < 8) {
+            {
+                const int tn = tap + (kc + PD) / 8, kn = (kc + PD) % 8;
+                if (tn < TAPS) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) bq[(kc + PD) & (RING - 1)][j] = wl(tap, kc + PD, j);
-            } else if (tap + 1 < TAPS) {
-#pragma unroll
-                for (int j = 0; j < RNX; j++) bq[(kc + PD) & (RING - 1)][j] = wl(tap + 1, kc + PD - 8, j);
+                    for (int j = 0; j < RNX; j++) bq[(tap * 8 + kc + PD) & (RING - 1)][j] = wl(tn, kn, j);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kc == 7) {
@@ -996,7 +1006,7 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* 
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
-                for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[kc & (RING - 1)][j], av[rt], acc[rt][j]);
+                for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[(tap * 8 + kc) & (RING - 1)][j], av[rt], acc[rt][j]);
                 if (kc < 7) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt] + (kc + 1 - (kc >= 4 ? 4 : 0)) * PLANE);
                 else if (tap + 1 < TAPS) av[rt] = *reinterpret_cast<const ex8*>(lds + abase[rt]);
             }
@@ -1009,6 +1019,53 @@ __device__ __forceinline__ void k_loop_256(const unsigned char* lds, const int* 
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
+    }
+}
+
+// The same 72 k-steps for the several-CU form, whose k-steps are one or two row tiles long (1 or 2 boards, RNX column tiles of a
+// quarter of the channels): with the activation fragment of step s + 1 requested after the MFMAs of step s, as above, a step is an
+// LDS round trip (≈100 cycles for 32-64 cycles of MFMAs: 5-7 us per layer measured).  Here the loop is fully unrolled — every ring slot
+// and every address offset a compile-time constant —, the activation fragments run AD steps ahead through a ring of four, the weight
+// fragments PD steps ahead through a ring of 16, and the lane's nine tap bases per row tile are read from the table once.  Same
+// order of accumulation per output: same bits.
+template <int RT, int RNX, int PLANE, typename ET, int PD = 12, int AD = 3, typename WL>
+__device__ __forceinline__ void k_loop_256_deep(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&acc)[RT][RNX], WL wl,
+                                                const typename Elem<ET>::x8* pre) {
+    typedef typename Elem<ET>::x8 ex8;
+    constexpr int TAPS = 9, STEPS = TAPS * 8, RING = 16, ARING = 4;
+    static_assert(PD < RING && AD < ARING, "prefetch distances");
+    int tb[TAPS][RT];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; tap++)
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) tb[tap][rt] = tap_table[(tap * RT + rt) * 64 + lane];
+    ex8 bq[RING][RNX];
+#pragma unroll
+    for (int d = 0; d < PD; d++)
+#pragma unroll
+        for (int j = 0; j < RNX; j++) bq[d][j] = pre ? pre[d * RNX + j] : wl(d / 8, d % 8, j);
+    ex8 av[ARING][RT];
+#pragma unroll
+    for (int d = 0; d < AD; d++)
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) av[d][rt] = *reinterpret_cast<const ex8*>(lds + tb[d / 8][rt] + (d % 8) * PLANE);
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+        if (st + PD < STEPS) {
+#pragma unroll
+            for (int j = 0; j < RNX; j++) bq[(st + PD) % RING][j] = wl((st + PD) / 8, (st + PD) % 8, j);
+        }
+        if (st + AD < STEPS) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+                av[(st + AD) % ARING][rt] = *reinterpret_cast<const ex8*>(lds + tb[(st + AD) / 8][rt] + ((st + AD) % 8) * PLANE);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int j = 0; j < RNX; j++) acc[rt][j] = Elem<ET>::mfma(bq[st % RING][j], av[st % ARING][rt], acc[rt][j]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1740,13 +1797,24 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 // TT = 1: compact tap table + ring loop (k_loop_256_ring): the form for 18 row tiles (6x6, 8 boards); needs PERM and 16 % P == 0.
 // NW = 4: four waves of 64 output channels, one per SIMD (A/B form, TZ_NET_W4=1): every activation fragment read from LDS feeds four
 // MFMAs instead of two; a wave then owns 208 accumulator registers on 5x5 and nothing fills its gaps.
-template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0, int TT = 0, int NW = 8>
+// SPLIT = 2 | 4: that many workgroups (CUs) share a board group, each computing 256 / SPLIT output channels of every conv (4 waves of
+// 16 / (4 SPLIT) column tiles) from the whole image, which every member holds; after a layer the members hand each other their planes
+// (a member's channels are 8 / SPLIT whole planes of the image) through a buffer in global memory.  For the Agent surface at the
+// reference's batch of 128, where one workgroup per board streams all 47 MB of weights through one CU's L1 (0.45 ms): with four
+// CUs each streams a quarter.  The hand-over is done by hand inside one XCD — plain stores, s_waitcnt vmcnt(0), an atomic that
+// the L2 executes, loads that bypass the L1: 1.4-1.9 us per layer (tools/cu_exchange_probe.hip) — because agent-scope release /
+// acquire writes back and invalidates the L2 on gfx950 (23-68 us per layer).  It rests on blocks b, b + 8, b + 16 .. being
+// dispatched to one XCD (round-robin over the 8 XCDs) and is used only where a wrong answer would show at once: tz_net_eval checks
+// the launch against the one-CU form in the tests, and a member that waits too long for its partners poisons its outputs with NaN
+// instead of hanging.  The accumulation order of an output does not depend on SPLIT (same k-loop, other RN): same bits as every other form.
+template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0, int TT = 0, int NW = 8, int SPLIT = 1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
     typedef typename Elem<ET>::x4 ex4;
     static_assert(!SP || sizeof(ET) == 2, "split precision runs on fp16 halves");
-    constexpr int RN = 16 / NW, TAPS = 9, LAYOUT = 1, NT = NW * 64;
+    constexpr int RN = 16 / (NW * SPLIT), TAPS = 9, LAYOUT = 1, NT = NW * 64;
     static_assert((NW == 8 || NW == 4) && (NW == 8 || SP == 0), "four waves: the fp16 / bf16 form only");
+    static_assert(SPLIT == 1 || ((SPLIT == 2 || SPLIT == 4) && NW == 4 && SP == 0 && TT == 0 && ABL == 0), "several CUs per board group: the four-wave fp16 / bf16 form");
     typedef RowMap<NB, P, PERM> RM;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
@@ -1764,15 +1832,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     tap_t* tap_table = reinterpret_cast<tap_t*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float));  // [TAPS][RT][64 lanes], TT = 1: [TAPS][RT][PPT]
     static_assert(!TT || (PERM && !SP && 16 % P == 0 && P >= 8), "compact tap table: square-major rows with whole 8-row runs per square");
     const int count = a.count_dev ? *a.count_dev : a.count_host;
-    const int pos0 = blockIdx.x * P;
-    if (pos0 >= count) return;
+    // SPLIT: members of a group are 8 blocks apart (one XCD); the grid is a multiple of 8 SPLIT blocks
+    const int group = SPLIT == 1 ? (int)blockIdx.x : ((int)blockIdx.x / (8 * SPLIT)) * 8 + (int)blockIdx.x % 8;
+    const int member = SPLIT == 1 ? 0 : ((int)blockIdx.x % (8 * SPLIT)) / 8;
+    const int pos0 = group * P;
+    if (pos0 >= count) return;   // the whole group leaves together
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, lr = lane & 15;
     const int valid_boards = min(P, count - pos0);
     const size_t m0 = (size_t)pos0 * NN;
-    const int ct0 = wave * RN;
+    const int ct0 = (member * NW + wave) * RN;
     const int lane16 = lane * 16;
+    int& xch_failed = *reinterpret_cast<int*>(lds + NPL * PLANE + 2 * RT * 16 * sizeof(float) + (size_t)TAPS * RT * 64 * sizeof(tap_t));   // SPLIT: 16 bytes behind the tap table
+    if (SPLIT > 1 && tid == 0) xch_failed = 0;
 
     // ---- the workgroup's packed states, copied into LDS in one round trip (plane 7 of the image is free until the first
     // conv's epilogue): game_repr walks every square of a state with data-dependent branches, which from global memory
@@ -1864,6 +1937,40 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
         if (R8 && block_output) *reinterpret_cast<int*>(lds + obase8[j] + 8 * PLANE + rt * 16 * LDS_ROWB) = r8;
     };
 
+    // SPLIT: after a layer's epilogue every member publishes its planes and takes the others' (see the template's comment)
+    int xround = 0;
+    auto exchange = [&]() {
+        if constexpr (SPLIT > 1) {
+            constexpr int MYPL = 8 / SPLIT, PL16 = PLANE / 16;
+            __syncthreads();   // the member's own planes are complete in LDS
+            unsigned char* gbase = a.xch + (size_t)(group * 2 + (xround & 1)) * 8 * PLANE;
+            for (int i = tid; i < MYPL * PL16; i += NT) {
+                const int off = (member * MYPL + i / PL16) * PLANE + (i % PL16) * 16;
+                *reinterpret_cast<uint4*>(gbase + off) = *reinterpret_cast<const uint4*>(lds + off);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged by the L2
+            __syncthreads();
+            if (tid == 0) {
+                unsigned* counter = a.xch_count + 32 * group;
+                const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(counter, 0, 128, 0x00020000);
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed by the L2
+                const unsigned want = (unsigned)SPLIT * (unsigned)(xround + 1);
+                int spins = 0;
+                while (!xch_failed && (unsigned)__builtin_amdgcn_raw_buffer_load_b32(crs, 0, 0, 17) < want) {   // sc0 sc1: past the L1
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 21)) xch_failed = 1;   // seconds: a partner is not coming; no more waiting, the outputs are poisoned below
+                }
+            }
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, 8 * PLANE, 0x00020000);
+            for (int i = tid; i < (8 - MYPL) * PL16; i += NT) {
+                const int off = ((member * MYPL + MYPL + i / PL16) % 8) * PLANE + (i % PL16) * 16;
+                *reinterpret_cast<u32x4*>(lds + off) = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 17);
+            }
+            xround++;
+        }
+    };
+
     f32x4 acc[RT][RN];
     f32x4 accc[SP ? RT : 1][RN];   // split precision: the correction accumulator (wl*xh + wh*xl), scaled by 2^-11 per layer
     // ---- first conv: cin_pad = 32*kc_in channels, 9*kc_in k-steps
@@ -1892,7 +1999,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
         // ---- RND input (RndNetwork::normalize, net5.rs:127): x / sum(x^2) over the whole position, written once per
         // position by the threads that built its squares; the sum adds the squares' partial sums in square order, so it
         // does not depend on the row order or on the boards per workgroup
-        if (a.rnd_in) {
+        if (a.rnd_in && member == 0) {
             for (int row = tid; row < RT * 16; row += NT) {
                 int board = 0, px = -1;
                 RM::decode(row, board, px);
@@ -2006,6 +2113,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     }
     // ---- residual tower
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
+    // SPLIT: the first weight fragments of the next layer are requested before the wait for the partners: their way from L2 overlaps the
+    // hand-over, and a layer's k-loop does not begin with a round trip of its own (41 of them per forward)
+    constexpr int KPD = SPLIT > 1 ? 12 : P <= 2 ? 6 : 2;
+    ex8 wpre[SPLIT > 1 ? KPD : 1][RN];
+    auto preload_weights = [&](int layer) {
+        if constexpr (SPLIT > 1) {
+#pragma unroll
+            for (int d = 0; d < KPD; d++)
+#pragma unroll
+                for (int j = 0; j < RN; j++)
+                    wpre[d][j] = __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, (layer * LAYER_FRAGS + d * 16 + (ct0 + j)) * 1024, 0));
+        }
+    };
+    if (a.nlayers > 0) preload_weights(0);
+    exchange();
     const __amdgpu_buffer_rsrc_t wrsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP == 1 ? a.w_lo : a.w), 0, a.nlayers * LAYER_FRAGS * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(SP == 2 ? a.w8 : reinterpret_cast<const unsigned char*>(a.w)), 0,
                                                                             a.nlayers * TAPS * 2 * 16 * 2 * 2048, 0x00020000);
@@ -2059,7 +2181,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             };
             if constexpr (TT) k_loop_256_ring<NB, P, RN, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, acc, wl);
             else if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 103)>(lds, tap_table, lane, acc, wl, reinterpret_cast<int*>(hscratch), wave, layer * 72);
-            else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, (P <= 2 ? 6 : 2)>(lds, tap_table, lane, acc, wl);
+            else if constexpr (SPLIT > 1) k_loop_256_deep<RT, RN, PLANE, ET, KPD>(lds, tap_table, lane, acc, wl, &wpre[0][0]);
+            else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, KPD>(lds, tap_table, lane, acc, wl);
         }
         if constexpr (ABL & 16) {
             if (layer == a.nlayers / 2 && lane == 0 && wave == 0 && a.dbg) a.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
@@ -2125,6 +2248,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
         if constexpr (ABL & 16) {
             if (layer == a.nlayers / 2 && lane == 0 && wave == 0 && a.dbg) a.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
         }
+        if (layer + 1 < a.nlayers) preload_weights(layer + 1);
+        exchange();
     }
     __syncthreads();  // the image now holds the tower's output
     if constexpr (ABL & 8) {
@@ -2212,16 +2337,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 sv += __shfl_xor(sv, d);
                 su += __shfl_xor(su, d);
             }
-            if (lane == 0) {
-                a.value[pos0 + pos] = tanhf(sv + lbv);
-                a.ube[pos0 + pos] = su + lbu;
+            if (lane == 0 && member == 0) {
+                const float poison = SPLIT > 1 && xch_failed ? __builtin_nanf("") : 0.0f;
+                a.value[pos0 + pos] = tanhf(sv + lbv) + poison;
+                a.ube[pos0 + pos] = su + lbu + poison;
             }
         }
     }
     // ---- policy conv: 16*RNPW output channels per wave, fp32 out
-    {
-        constexpr int RNPW = RNP * 8 / NW;   // column tiles of a wave
-        const int ctp = wave * RNPW;
+    constexpr int PM = SPLIT == 1 ? 1 : (8 * RNP / NW < SPLIT ? 8 * RNP / NW : SPLIT);   // members that take part in the policy conv
+    if (member < PM) {
+        constexpr int RNPW = RNP * 8 / (NW * PM);   // column tiles of a wave
+        const int ctp = (member * NW + wave) * RNPW;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w_pol), 0, TAPS * 8 * 8 * RNP * 1024, 0x00020000);
         f32x4 pacc[RT][RNPW];
 #pragma unroll
@@ -2280,6 +2407,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             };
             if constexpr (TT) k_loop_256_ring<NB, P, RNPW, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, pacc, wlp);
             else if constexpr (PERM) k_loop_256_skip<NB, P, RNPW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
+            else if constexpr (SPLIT > 1) k_loop_256_deep<RT, RNPW, PLANE, ET>(lds, tap_table, lane, pacc, wlp, nullptr);
             else k_loop_256<NB, RT, RNPW, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
         }
 #pragma unroll
@@ -2289,8 +2417,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             for (int rt = 0; rt < RT; rt++) {
                 int board = 0, sq = -1;
                 RM::decode(rt * 16 + lr, board, sq);
-                if (sq >= 0 && board < valid_boards)
+                if (sq >= 0 && board < valid_boards) {
+                    if (SPLIT > 1 && xch_failed) pacc[rt][j][0] = __builtin_nanf("");
                     *reinterpret_cast<f32x4*>(a.policy_out + (m0 + board * NN + sq) * a.pol_stride + cbase) = pacc[rt][j];
+                }
             }
         }
     }
@@ -3066,6 +3196,10 @@ int linear_grouped_bf16(int precision, const uint16_t* w, const float* bias, int
     a.w_z_frags = a.kc_total * a.ct_total;
     a.bias_z = cout_pad;
     a.out_z = out_z;
+    if (max_positions <= 128) {   // the Agent surface's batches: 32 instead of 128 rows per workgroup, four times the workgroups (8 -> 32 per layer at batch 128)
+        if (prec_is_f16(precision)) return launch_conv<1, 32, 8, 2, 1, false, false, 0, 1, _Float16>(a, max_positions, cout_pad / 256, st);
+        return launch_conv<1, 32, 8, 2, 1, false, false>(a, max_positions, cout_pad / 256, st);
+    }
     if (prec_is_f16(precision)) return launch_conv<1, 128, 8, 2, 1, false, false, 0, 1, _Float16>(a, max_positions, cout_pad / 256, st);
     return launch_conv<1, 128, 8, 2, 1, false, false>(a, max_positions, cout_pad / 256, st);
 }
@@ -3198,14 +3332,17 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
     return mode;
 }
 
-template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0, int NW = 8>
+constexpr int NET_SPLIT_MAX_GROUPS = 64;           // several CUs per board group: at most 64 groups x 4 members = one workgroup per CU
+constexpr size_t NET_SPLIT_PLANE_BYTES = 4608;     // the largest image plane of those forms (5x5, 2 boards: 72 rows of 64 B)
+
+template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0, int NW = 8, int SPLIT = 1>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
     constexpr int RT = RowMap<NB, P, PERM>::RT, LROWS = RT * 16 + 8;
     constexpr bool ROWTAB = SP != 0 && NB == 6 && P == 4;   // as in the kernel: 8-bit table, no remainder planes
     constexpr size_t tap_bytes = TT ? (size_t)9 * RT * RowMap<NB, P, PERM>::PPT * sizeof(int) : (size_t)9 * RT * 64 * (ROWTAB ? 1 : SP == 2 ? sizeof(uint16_t) : sizeof(int));
-    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP == 2 ? (NB == 6 ? 16 : 20) : SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes;  // image + head scratch + tap table
+    constexpr size_t smem = (size_t)LROWS * LDS_ROWB * (SP == 2 ? (NB == 6 ? 16 : 20) : SP ? 16 : 8) + 2 * RT * 16 * sizeof(float) + tap_bytes + (SPLIT > 1 ? 16 : 0);  // image + head scratch + tap table (+ the exchange's flag)
     static_assert(smem <= 160 * 1024, "net kernel: the LDS image does not fit a CU");
-    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT, NW>;
+    auto kern = net_mfma_kernel<NB, P, RNP, ET, PERM, SP, ABL, TT, NW, SPLIT>;
     static bool attr_done[64] = {};   // per device: a function attribute belongs to the device's copy of the module
     int attr_dev = 0;
     TZ_HIP(hipGetDevice(&attr_dev));
@@ -3214,7 +3351,14 @@ int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
         TZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((max_positions + P - 1) / P), dim3(NW * 64), smem, st, a);
+    int blocks = (max_positions + P - 1) / P;
+    if (SPLIT > 1) {   // whole octets of groups (members of a group sit 8 blocks apart), counters at zero
+        const int groups = (blocks + 7) / 8 * 8;
+        if (groups > NET_SPLIT_MAX_GROUPS || !a.xch || !a.xch_count) return tz_fail(TZ_EINVAL, "net launch: the several-CU form is for small batches");
+        TZ_HIP(hipMemsetAsync(a.xch_count, 0, (size_t)groups * 128, st));
+        blocks = groups * SPLIT;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NW * 64), smem, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tz_fail(TZ_EDEVICE, std::string("net launch: ") + hipGetErrorString(e));
     return TZ_OK;
@@ -3294,6 +3438,11 @@ template <typename ET>
 int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t st) {
     const bool sq = net_square_major();
     const int small = net_small_p(max_positions);
+    // the Agent surface at the reference's batch (tz_net_eval, count known on the host): four CUs per board group
+    if (net->n == 5 && a.xch && !a.count_dev && a.count_host <= 2 * NET_SPLIT_MAX_GROUPS && sizeof(ET) == 2) {
+        if (a.count_host <= NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, ET, false, 1, 0, 0, 0, 4, 4>(a, a.count_host, st);
+        return launch_net<5, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, a.count_host, st);
+    }
     if (net->n == 5 && small == 1) return launch_net<5, 1, ET, false, 1>(a, max_positions, st);
     if (net->n == 5 && small == 2) return launch_net<5, 1, ET, false, 2>(a, max_positions, st);
     if (net->n == 5 && small == 4) return launch_net<5, 1, ET, false, 4>(a, max_positions, st);
@@ -3341,6 +3490,7 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
 // RND input from the fused kernel: net5 only (in_size 800 = 25 squares x 32 planes, no K padding, 8 planes per 16-B store)
 bool net_fused_writes_rnd_input(const tz_net* net) {
     static const bool separate = getenv("TZ_RND_PREP_KERNEL") != nullptr;   // A/B: the separate rnd_prep_state_kernel
+    if (net->eval_split) return false;   // tz_net_eval at small batches: the RND MLP runs beside the net kernel, from its own input kernel
     return !separate && net->has_rnd && net->n == 5 && net->cin % 8 == 0 && (net->cin * net->nn) % 32 == 0;
 }
 
@@ -3379,6 +3529,8 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
     a.seeds = net->seeds;
+    a.xch = net->eval_split ? static_cast<unsigned char*>(net->xch) : nullptr;
+    a.xch_count = net->eval_split ? net->xch_count : nullptr;
 #ifdef TZ_ABLATIONS
     if (getenv("TZ_NET_ABL") && (atoi(getenv("TZ_NET_ABL")) == 8 || (atoi(getenv("TZ_NET_ABL")) & 16))) {
         if (!net->dbg_buf) TZ_HIP(hipMalloc(&net->dbg_buf, (size_t)65536 * 4 * sizeof(unsigned long long)));
@@ -3495,6 +3647,37 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
     if (need_planes && (rc = encode(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
     void *x = net->act_a, *t = net->act_b, *y = net->act_c;
     const bool split = prec_is_split(net->precision);
+    const int rnd_in_pad = (net->cin * nn + 31) / 32 * 32;
+    // tz_net_eval at small batches (several CUs per board group): the RND MLP does not wait for the net kernel — it reads the packed
+    // states, not the trunk — so it runs on a stream of its own beside it (45 of a call's 460 us), and only rnd_finish joins the two
+    const bool rnd_ahead = net->eval_split && net->has_rnd && bf && net->n == 5 && net->stream_rnd;
+    auto rnd_mlp = [&](hipStream_t rs) -> int {
+        // 3 launches: input planes straight from the packed states, layer 1 of both nets as one GEMM,
+        // layers 2 and 3 as grouped launches (blockIdx.z = net)
+        const bool fused_wrote_it = net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split) && net_fused_writes_rnd_input(net);
+        switch (net->n) {
+            case 5:
+                if (fused_wrote_it) break;   // net_mfma_kernel wrote x / sum(x^2) while it built the planes
+                if (prec_is_f16(net->precision))
+                    rnd_prep_state_kernel<5, _Float16><<<max_positions, 64, 0, rs>>>(states, gidx, count_dev, count_host, net->cin, rnd_in_pad, (_Float16*)net->rnd_in);
+                else
+                    rnd_prep_state_kernel<5, __bf16><<<max_positions, 64, 0, rs>>>(states, gidx, count_dev, count_host, net->cin, rnd_in_pad, (__bf16*)net->rnd_in);
+                break;
+            default: return tz_fail(TZ_EINVAL, "RND is a net5 (5x5) feature");
+        }
+        float* o = net->rnd_out;
+        if ((rc = linear_grouped_bf16(net->precision, net->rndw[0], net->rndb[0], 1, rnd_in_pad, 2048, net->rnd_in, rnd_in_pad, 0, net->rnd_h1, 2048, 0,
+                                      true, false, count_dev, count_host, max_positions, rs)))
+            return rc;
+        if ((rc = linear_grouped_bf16(net->precision, net->rndw[1], net->rndb[1], 2, 1024, 1024, net->rnd_h1, 2048, 1024, net->rnd_h2, 2048, 1024,
+                                      true, false, count_dev, count_host, max_positions, rs)))
+            return rc;
+        if ((rc = linear_grouped_bf16(net->precision, net->rndw[2], net->rndb[2], 2, 1024, 512, net->rnd_h2, 2048, 1024, o, 1024, 512, false, true,
+                                      count_dev, count_host, max_positions, rs)))
+            return rc;
+        return TZ_OK;
+    };
+
     if (split && !(net->blocks > 0 && (net->tower_w_lo || net->tower_w8)))
         return tz_fail(TZ_EINVAL, "forward: TZ_PREC_F16X2 / TZ_PREC_F16C8 / TZ_PREC_F16C6 need a network with at least one residual block");
     if (bf && net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split)) {
@@ -3503,6 +3686,12 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
             TZ_HIP(hipEventCreate(&e0));
             TZ_HIP(hipEventCreate(&e1));
             TZ_HIP(hipEventRecord(e0, st));
+        }
+        if (rnd_ahead) {
+            TZ_HIP(hipEventRecord(net->ev_in, st));            // the states have arrived (tz_net_eval's copy is ahead of this on st)
+            TZ_HIP(hipStreamWaitEvent(net->stream_rnd, net->ev_in, 0));
+            if ((rc = rnd_mlp(net->stream_rnd))) return rc;
+            TZ_HIP(hipEventRecord(net->ev_rnd, net->stream_rnd));
         }
         if ((rc = net_fused(net, states, gidx, count_dev, count_host, max_positions, st))) return rc;
         if (net->profile) {
@@ -3582,29 +3771,9 @@ int tz_net_forward_device(tz_net* net, const tz_state* states, const int32_t* gi
         const int in_size = net->cin * nn, in_pad = (in_size + 31) / 32 * 32;
         float* outs[2] = {net->rnd_out, net->rnd_out + (size_t)net->max_batch * 512};
         if (bf) {
-            // 3 launches: input planes straight from the packed states, layer 1 of both nets as one GEMM,
-            // layers 2 and 3 as grouped launches (blockIdx.z = net)
-            const bool fused_wrote_it = net->blocks > 0 && net->tower_w && (net_fused_mode() == 2 || split) && net_fused_writes_rnd_input(net);
-            switch (net->n) {
-                case 5:
-                    if (fused_wrote_it) break;   // net_mfma_kernel wrote x / sum(x^2) while it built the planes
-                    if (prec_is_f16(net->precision))
-                        rnd_prep_state_kernel<5, _Float16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (_Float16*)net->rnd_in);
-                    else
-                        rnd_prep_state_kernel<5, __bf16><<<max_positions, 64, 0, st>>>(states, gidx, count_dev, count_host, net->cin, in_pad, (__bf16*)net->rnd_in);
-                    break;
-                default: return tz_fail(TZ_EINVAL, "RND is a net5 (5x5) feature");
-            }
+            if (!rnd_ahead && (rc = rnd_mlp(st))) return rc;
+            if (rnd_ahead) TZ_HIP(hipStreamWaitEvent(st, net->ev_rnd, 0));
             float* o = net->rnd_out;
-            if ((rc = linear_grouped_bf16(net->precision, net->rndw[0], net->rndb[0], 1, in_pad, 2048, net->rnd_in, in_pad, 0, net->rnd_h1, 2048, 0,
-                                          true, false, count_dev, count_host, max_positions, st)))
-                return rc;
-            if ((rc = linear_grouped_bf16(net->precision, net->rndw[1], net->rndb[1], 2, 1024, 1024, net->rnd_h1, 2048, 1024, net->rnd_h2, 2048, 1024,
-                                          true, false, count_dev, count_host, max_positions, st)))
-                return rc;
-            if ((rc = linear_grouped_bf16(net->precision, net->rndw[2], net->rndb[2], 2, 1024, 512, net->rnd_h2, 2048, 1024, o, 1024, 512, false, true,
-                                          count_dev, count_host, max_positions, st)))
-                return rc;
             rnd_finish_kernel<<<max_positions, 64, 0, st>>>(o, o + 512, net->ube, count_dev, count_host, 512, 1024, net->rnd_min,
                                                             net->rnd_max, net->variance);
         } else {
@@ -4323,9 +4492,12 @@ int tz_net_destroy(tz_net* net) {
     old.simhash = net->simhash;
     free_weights(old);
     void* bufs[] = {net->act_a, net->act_b, net->act_c, net->planes, net->policy_out, net->value, net->ube,
-                    net->variance, net->aux, net->rnd_in, net->rnd_h1, net->rnd_h2, net->rnd_out, net->bitset, net->seeds};
+                    net->variance, net->aux, net->rnd_in, net->rnd_h1, net->rnd_h2, net->rnd_out, net->bitset, net->seeds, net->xch, net->xch_count};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (net->stream_rnd) (void)hipStreamDestroy(net->stream_rnd);
+    if (net->ev_in) (void)hipEventDestroy(net->ev_in);
+    if (net->ev_rnd) (void)hipEventDestroy(net->ev_rnd);
     for (auto& ev : net->conv_events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -4390,7 +4562,22 @@ int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* 
     hipStream_t st = net->stream;
     TZ_HIP(hipMemcpyAsync(dev, host, in_bytes, hipMemcpyHostToDevice, st));
     NetOut o;
+    // several CUs per board group for batches up to 128 on 5x5 in the 16-bit storage types (TZ_NET_SPLIT=0: one CU per group, A/B)
+    static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
+    if (!split_off && net->n == 5 && batch <= 2 * NET_SPLIT_MAX_GROUPS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
+        net->blocks > 0 && net_fused_mode() == 2) {
+        if (!net->xch) {
+            TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 8 * NET_SPLIT_PLANE_BYTES));
+            TZ_HIP(hipMalloc((void**)&net->xch_count, (size_t)NET_SPLIT_MAX_GROUPS * 128));
+            if (hipStreamCreateWithFlags(&net->stream_rnd, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&net->ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&net->ev_rnd, hipEventDisableTiming) != hipSuccess)
+                net->stream_rnd = nullptr;   // without it the RND MLP follows the net kernel on its stream, as in every other path
+        }
+        net->eval_split = true;
+    }
     rc = tz_net_forward_device(net, reinterpret_cast<const tz_state*>(dev + o_states), nullptr, nullptr, batch, batch, st, &o);
+    net->eval_split = false;
     if (rc) return rc;
     eval_pack_kernel<<<(int)((cells + 255) / 256), 256, 0, st>>>(o.policy, net->nn, o.policy_stride, reinterpret_cast<const uint16_t*>(dev + o_legal),
                                                                reinterpret_cast<const int32_t*>(dev + o_cnt), amax, batch, o.value, o.variance,

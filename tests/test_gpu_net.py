@@ -472,3 +472,46 @@ def test_net_launch_forms_are_bit_identical():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "net_rows_ab.py"), "3", "5", "6"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "BIT-IDENTICAL" in out.stdout, out.stdout + out.stderr
+
+
+def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle):
+    """tz_net_eval on 5x5 at batches up to 128 (the reference's batch, selfplay/src/main.rs:37) runs net_mfma_kernel's SPLIT form: four
+    workgroups per group of one or two boards, each computing a quarter of every conv's output channels and handing its planes to the
+    others after every layer through a buffer that the four meet in by hand inside one XCD's L2 (csrc/tz_nn.hip).  The k-loop of an
+    output is the one-CU form's, so logits, value and variance must equal — bit for bit — what the same positions give through
+    tz_net_forward_raw (one CU per group) and through tz_net_eval with TZ_NET_SPLIT=0, at every batch size incl. partial groups and
+    octets, in both 16-bit storage types, and call after call (a stale read of a partner's planes would differ from run to run)."""
+    import subprocess
+    import sys
+
+    A = require_gpu()
+    from takzero_amd import weights as W
+
+    states = random_positions(oracle, O, 5, 4, 128, 17, max_ply=30)
+    arr = O.states_array(states)
+    acts = [O.possible_moves(oracle, s) for s in states]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import takzero_amd.api as A; from takzero_amd import weights as W\n"
+            "d = np.load(sys.argv[1], allow_pickle=True); arr = d['arr'].view(A._lib.STATE_DTYPE).reshape(-1); acts = list(d['acts'])\n"
+            "net = A.Net(arch=A.ARCH_NET5, precision=int(sys.argv[2])).load_tensors(W.init_weights(W.ARCH_NET5, seed=5))\n"
+            "out = {}\n"
+            "for B in (1, 7, 64, 65, 100, 128):\n"
+            "    l, v, u = net.policy_value_uncertainty(arr[:B], acts[:B]); out['l%%d' %% B] = np.concatenate(l); out['v%%d' %% B] = v; out['u%%d' %% B] = u\n"
+            "np.savez(sys.argv[3], **out)\n") % (root, os.path.join(root, "tests"))
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, "in.npz"), arr=np.frombuffer(arr.tobytes(), np.uint8), acts=np.array(acts, dtype=object))
+        for prec in (A.PREC_F16, A.PREC_BF16):
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "in.npz"), str(prec), os.path.join(d, "off.npz")],
+                               env=dict(os.environ, TZ_NET_SPLIT="0"), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-1500:]
+            off = np.load(os.path.join(d, "off.npz"))
+            net = A.Net(arch=A.ARCH_NET5, precision=prec).load_tensors(W.init_weights(W.ARCH_NET5, seed=5))
+            pol, val, _ = net.forward_raw(arr)
+            for B in (1, 7, 64, 65, 100, 128):
+                for rep in range(6 if B == 128 else 2):
+                    l, v, u = net.policy_value_uncertainty(arr[:B], acts[:B])
+                    assert np.array_equal(np.concatenate(l), off["l%d" % B]) and np.array_equal(v, off["v%d" % B]) and np.array_equal(u, off["u%d" % B]), (prec, B, rep)
+                    assert all(np.array_equal(l[i], pol[i, np.asarray(acts[i], np.int64)]) for i in range(B)) and np.array_equal(v, val[:B])
+            net.close()
