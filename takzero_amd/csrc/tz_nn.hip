@@ -3439,9 +3439,9 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
     const bool sq = net_square_major();
     const int small = net_small_p(max_positions);
     // the Agent surface at the reference's batch (tz_net_eval, count known on the host): four CUs per board group
-    if (net->n == 5 && a.xch && !a.count_dev && a.count_host <= 2 * NET_SPLIT_MAX_GROUPS && sizeof(ET) == 2) {
-        if (a.count_host <= NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, ET, false, 1, 0, 0, 0, 4, 4>(a, a.count_host, st);
-        return launch_net<5, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, a.count_host, st);
+    if (net->n == 5 && a.xch && max_positions <= 2 * NET_SPLIT_MAX_GROUPS && sizeof(ET) == 2) {
+        if (max_positions <= NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, ET, false, 1, 0, 0, 0, 4, 4>(a, max_positions, st);
+        return launch_net<5, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, max_positions, st);
     }
     if (net->n == 5 && small == 1) return launch_net<5, 1, ET, false, 1>(a, max_positions, st);
     if (net->n == 5 && small == 2) return launch_net<5, 1, ET, false, 2>(a, max_positions, st);
@@ -3529,8 +3529,19 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
     a.seeds = net->seeds;
-    a.xch = net->eval_split ? static_cast<unsigned char*>(net->xch) : nullptr;
-    a.xch_count = net->eval_split ? net->xch_count : nullptr;
+    // several CUs per board group (net_mfma_kernel SPLIT): 5x5, 16-bit storage, up to 128 positions — tz_net_eval at the reference's batch
+    // and searches of that width (the reference's selfplay runs 128 games: selfplay/src/main.rs:37).  TZ_NET_SPLIT=0: one CU per group (A/B)
+    a.xch = nullptr;
+    a.xch_count = nullptr;
+    static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
+    if (!split_off && net->n == 5 && max_positions <= 2 * NET_SPLIT_MAX_GROUPS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) {
+        if (!net->xch) {   // first use; a search's first two steps run outside its graph capture, so this is never inside one
+            TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 8 * NET_SPLIT_PLANE_BYTES));
+            TZ_HIP(hipMalloc((void**)&net->xch_count, (size_t)NET_SPLIT_MAX_GROUPS * 128));
+        }
+        a.xch = static_cast<unsigned char*>(net->xch);
+        a.xch_count = net->xch_count;
+    }
 #ifdef TZ_ABLATIONS
     if (getenv("TZ_NET_ABL") && (atoi(getenv("TZ_NET_ABL")) == 8 || (atoi(getenv("TZ_NET_ABL")) & 16))) {
         if (!net->dbg_buf) TZ_HIP(hipMalloc(&net->dbg_buf, (size_t)65536 * 4 * sizeof(unsigned long long)));
@@ -4566,9 +4577,7 @@ int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* 
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
     if (!split_off && net->n == 5 && batch <= 2 * NET_SPLIT_MAX_GROUPS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
         net->blocks > 0 && net_fused_mode() == 2) {
-        if (!net->xch) {
-            TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 8 * NET_SPLIT_PLANE_BYTES));
-            TZ_HIP(hipMalloc((void**)&net->xch_count, (size_t)NET_SPLIT_MAX_GROUPS * 128));
+        if (!net->stream_rnd && !net->ev_in) {
             if (hipStreamCreateWithFlags(&net->stream_rnd, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&net->ev_in, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&net->ev_rnd, hipEventDisableTiming) != hipSuccess)
