@@ -2181,7 +2181,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             };
             if constexpr (TT) k_loop_256_ring<NB, P, RN, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, acc, wl);
             else if constexpr (PERM) k_loop_256_skip<NB, P, RN, PLANE, ET, (ABL & 103)>(lds, tap_table, lane, acc, wl, reinterpret_cast<int*>(hscratch), wave, layer * 72);
-            else if constexpr (SPLIT > 1) k_loop_256_deep<RT, RN, PLANE, ET, KPD>(lds, tap_table, lane, acc, wl, &wpre[0][0]);
+            else if constexpr (SPLIT > 1 && RT <= 4) k_loop_256_deep<RT, RN, PLANE, ET, KPD>(lds, tap_table, lane, acc, wl, &wpre[0][0]);
+            else if constexpr (SPLIT > 1) k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, KPD>(lds, tap_table, lane, acc, wl, &wpre[0][0]);   // 4 and 8 boards: k-steps long enough for one fragment ahead
             else k_loop_256<NB, RT, RN, ROWS, ZROW, PLANE, ET, KPD>(lds, tap_table, lane, acc, wl);
         }
         if constexpr (ABL & 16) {
@@ -2407,7 +2408,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             };
             if constexpr (TT) k_loop_256_ring<NB, P, RNPW, PLANE, ET, 6>(lds, tap_table, tslot, lane_const, pacc, wlp);
             else if constexpr (PERM) k_loop_256_skip<NB, P, RNPW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
-            else if constexpr (SPLIT > 1) k_loop_256_deep<RT, RNPW, PLANE, ET>(lds, tap_table, lane, pacc, wlp, nullptr);
+            else if constexpr (SPLIT > 1 && RT <= 4) k_loop_256_deep<RT, RNPW, PLANE, ET>(lds, tap_table, lane, pacc, wlp, nullptr);
+            else if constexpr (SPLIT > 1) k_loop_256<NB, RT, RNPW, ROWS, ZROW, PLANE, ET, 12>(lds, tap_table, lane, pacc, wlp);
             else k_loop_256<NB, RT, RNPW, ROWS, ZROW, PLANE, ET>(lds, tap_table, lane, pacc, wlp);
         }
 #pragma unroll
@@ -3333,7 +3335,8 @@ int net_fused_mode() {  // 2: whole trunk + heads in one launch (default); 1: fu
 }
 
 constexpr int NET_SPLIT_MAX_GROUPS = 64;           // several CUs per board group: at most 64 groups x 4 members = one workgroup per CU
-constexpr size_t NET_SPLIT_PLANE_BYTES = 4608;     // the largest image plane of those forms (5x5, 2 boards: 72 rows of 64 B)
+constexpr size_t NET_SPLIT_PLANE_BYTES = 7680;     // the largest image plane of those forms (5x5, 4 boards: 120 rows of 64 B)
+constexpr int NET_SPLIT_MAX_POSITIONS = 4 * NET_SPLIT_MAX_GROUPS;   // 64 groups of 1, 2 or 4 boards (with 8 the one-CU forms are faster: 0.63 against 0.69 ms per simulation of 512 games)
 
 template <int NB, int RNP, typename ET, bool PERM, int P = ppt_for(NB), int SP = 0, int ABL = 0, int TT = 0, int NW = 8, int SPLIT = 1>
 int launch_net(const NetArgs& a, int max_positions, hipStream_t st) {
@@ -3439,9 +3442,10 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
     const bool sq = net_square_major();
     const int small = net_small_p(max_positions);
     // the Agent surface at the reference's batch (tz_net_eval, count known on the host): four CUs per board group
-    if (net->n == 5 && a.xch && max_positions <= 2 * NET_SPLIT_MAX_GROUPS && sizeof(ET) == 2) {
+    if (net->n == 5 && a.xch && max_positions <= NET_SPLIT_MAX_POSITIONS && sizeof(ET) == 2) {   // 64 groups x 4 CUs: 1, 2 or 4 boards per group
         if (max_positions <= NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, ET, false, 1, 0, 0, 0, 4, 4>(a, max_positions, st);
-        return launch_net<5, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, max_positions, st);
+        if (max_positions <= 2 * NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, max_positions, st);
+        return launch_net<5, 1, ET, false, 4, 0, 0, 0, 4, 4>(a, max_positions, st);
     }
     if (net->n == 5 && small == 1) return launch_net<5, 1, ET, false, 1>(a, max_positions, st);
     if (net->n == 5 && small == 2) return launch_net<5, 1, ET, false, 2>(a, max_positions, st);
@@ -3529,12 +3533,12 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
     a.seeds = net->seeds;
-    // several CUs per board group (net_mfma_kernel SPLIT): 5x5, 16-bit storage, up to 128 positions — tz_net_eval at the reference's batch
-    // and searches of that width (the reference's selfplay runs 128 games: selfplay/src/main.rs:37).  TZ_NET_SPLIT=0: one CU per group (A/B)
+    // several CUs per board group (net_mfma_kernel SPLIT): 5x5, 16-bit storage, up to 256 positions — tz_net_eval at the reference's batch
+    // and searches of such widths (the reference's selfplay runs 128 games: selfplay/src/main.rs:37).  TZ_NET_SPLIT=0: one CU per group (A/B)
     a.xch = nullptr;
     a.xch_count = nullptr;
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
-    if (!split_off && net->n == 5 && max_positions <= 2 * NET_SPLIT_MAX_GROUPS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) {
+    if (!split_off && net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) {
         if (!net->xch) {   // first use; a search's first two steps run outside its graph capture, so this is never inside one
             TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 8 * NET_SPLIT_PLANE_BYTES));
             TZ_HIP(hipMalloc((void**)&net->xch_count, (size_t)NET_SPLIT_MAX_GROUPS * 128));
@@ -4575,7 +4579,7 @@ int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* 
     NetOut o;
     // several CUs per board group for batches up to 128 on 5x5 in the 16-bit storage types (TZ_NET_SPLIT=0: one CU per group, A/B)
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
-    if (!split_off && net->n == 5 && batch <= 2 * NET_SPLIT_MAX_GROUPS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
+    if (!split_off && net->n == 5 && batch <= NET_SPLIT_MAX_POSITIONS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
         net->blocks > 0 && net_fused_mode() == 2) {
         if (!net->stream_rnd && !net->ev_in) {
             if (hipStreamCreateWithFlags(&net->stream_rnd, hipStreamNonBlocking) != hipSuccess ||
