@@ -423,6 +423,24 @@ def main():
                                             "dominant_kernel": prof["conv_ms"] / max(1, prof["steps"]),
                                             "wall": 1000.0 * dt / max(1.0, (sims1 - sims0) / args.games)}
             out["net_flops_frac_of_peak"] = (evals / dt_max) * FLOP_PER_POSITION / (world * PEAK_BF16_TFLOPS * 1e12)
+        if world == 1 and not args.no_precision_report and args.games >= 256:
+            # the Agent surface on its own (tz_net_eval: host states and legal moves in, host logits / value / variance out), the drop-in point
+            # for a host that keeps the reference's CPU BatchedMCTS: per call at the reference's batch of 128 (selfplay/src/main.rs:37) and at 1.
+            # Not part of `value`.
+            try:
+                states = mcts.get_positions()
+                ch, info = mcts.root_children(), mcts.root_info()
+                acts = [ch["move_idx"][g, :info["n_children"][g]] for g in range(256)]
+                out["agent_surface"] = {"what": "tz_net_eval, PCIe and staging included; up to 256 positions run on four CUs per board group"}
+                for b in (128, 1):
+                    net.policy_value_uncertainty(states[:b], acts[:b])
+                    t0 = time.perf_counter()
+                    for _ in range(40):
+                        net.policy_value_uncertainty(states[:b], acts[:b])
+                    per = (time.perf_counter() - t0) / 40
+                    out["agent_surface"]["batch_%d" % b] = {"ms_per_call": 1000.0 * per, "positions_per_s": b / per}
+            except Exception as e:
+                out["agent_surface"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

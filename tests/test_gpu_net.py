@@ -474,7 +474,8 @@ def test_net_launch_forms_are_bit_identical():
     assert out.returncode == 0 and "BIT-IDENTICAL" in out.stdout, out.stdout + out.stderr
 
 
-def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle):
+@pytest.mark.parametrize("n", [5, 6])
+def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle, n):
     """tz_net_eval on 5x5 at batches up to 256 (the reference's batch is 128, selfplay/src/main.rs:37) runs net_mfma_kernel's SPLIT form: four
     workgroups per group of one, two or four boards, each computing a quarter of every conv's output channels and handing its planes to the
     others after every layer through a buffer that the four meet in by hand inside one XCD's L2 (csrc/tz_nn.hip).  The k-loop of an
@@ -487,18 +488,19 @@ def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle)
     A = require_gpu()
     from takzero_amd import weights as W
 
-    states = random_positions(oracle, O, 5, 4, 512, 17, max_ply=30)
+    arch, wname = (A.ARCH_NET5, "ARCH_NET5") if n == 5 else (A.ARCH_NET6_SIMHASH, "ARCH_NET6_SIMHASH")   # 6x6: groups of one or two boards, up to 128 positions
+    states = random_positions(oracle, O, n, 4, 512 if n == 5 else 200, 17, max_ply=30)
     arr = O.states_array(states)
     acts = [O.possible_moves(oracle, s) for s in states]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sizes = (1, 7, 64, 65, 100, 128, 129, 256, 300, 512)   # 1, 2 and 4 boards per group, partial groups and octets of groups; past 256 the one-CU forms
+    sizes = (1, 7, 64, 65, 100, 128, 129, 256, 300, 512) if n == 5 else (1, 7, 64, 65, 128, 200)   # 1, 2 and 4 boards per group, partial groups and octets of groups; past 256 the one-CU forms
     code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; import takzero_amd.api as A; from takzero_amd import weights as W\n"
             "d = np.load(sys.argv[1], allow_pickle=True); arr = d['arr'].view(A._lib.STATE_DTYPE).reshape(-1); acts = list(d['acts'])\n"
-            "net = A.Net(arch=A.ARCH_NET5, precision=int(sys.argv[2])).load_tensors(W.init_weights(W.ARCH_NET5, seed=5))\n"
+            "net = A.Net(arch=A.%s, precision=int(sys.argv[2])).load_tensors(W.init_weights(W.%s, seed=5))\n"
             "out = {}\n"
             "for B in %r:\n"
             "    l, v, u = net.policy_value_uncertainty(arr[:B], acts[:B]); out['l%%d' %% B] = np.concatenate(l); out['v%%d' %% B] = v; out['u%%d' %% B] = u\n"
-            "np.savez(sys.argv[3], **out)\n") % (root, os.path.join(root, "tests"), sizes)
+            "np.savez(sys.argv[3], **out)\n") % (root, os.path.join(root, "tests"), wname, wname, sizes)
     import tempfile
 
     with tempfile.TemporaryDirectory() as d:
@@ -508,10 +510,10 @@ def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle)
                                env=dict(os.environ, TZ_NET_SPLIT="0"), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-1500:]
             off = np.load(os.path.join(d, "off.npz"))
-            net = A.Net(arch=A.ARCH_NET5, precision=prec).load_tensors(W.init_weights(W.ARCH_NET5, seed=5))
+            net = A.Net(arch=arch, precision=prec).load_tensors(W.init_weights(getattr(W, wname), seed=5))
             pol, val, _ = net.forward_raw(arr)
             for B in sizes:
-                for rep in range(6 if B in (128, 512) else 2):
+                for rep in range(6 if B == 128 else 2):
                     l, v, u = net.policy_value_uncertainty(arr[:B], acts[:B])
                     assert np.array_equal(np.concatenate(l), off["l%d" % B]) and np.array_equal(v, off["v%d" % B]) and np.array_equal(u, off["u%d" % B]), (prec, B, rep)
                     assert all(np.array_equal(l[i], pol[i, np.asarray(acts[i], np.int64)]) for i in range(B)) and np.array_equal(v, val[:B])
