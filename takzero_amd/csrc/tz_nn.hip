@@ -3447,6 +3447,10 @@ int net_fused_et(tz_net* net, const NetArgs& a, int max_positions, hipStream_t s
         if (max_positions <= 2 * NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, max_positions, st);
         return launch_net<5, 1, ET, false, 4, 0, 0, 0, 4, 4>(a, max_positions, st);
     }
+    if (net->n == 4 && a.xch && max_positions <= 2 * NET_SPLIT_MAX_GROUPS && sizeof(ET) == 2) {   // 4x4: 1 or 2 boards per group of four CUs
+        if (max_positions <= NET_SPLIT_MAX_GROUPS) return launch_net<4, 1, ET, false, 1, 0, 0, 0, 4, 4>(a, max_positions, st);
+        return launch_net<4, 1, ET, false, 2, 0, 0, 0, 4, 4>(a, max_positions, st);
+    }
     if (net->n == 6 && a.xch && max_positions <= 2 * NET_SPLIT_MAX_GROUPS && sizeof(ET) == 2) {   // 6x6: 1 or 2 boards per group of four CUs
         if (max_positions <= NET_SPLIT_MAX_GROUPS) return launch_net<6, 2, ET, false, 1, 0, 0, 0, 4, 4>(a, max_positions, st);
         return launch_net<6, 2, ET, false, 2, 0, 0, 0, 4, 4>(a, max_positions, st);
@@ -3537,12 +3541,12 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.c8_scales = net->c8_scales;
     a.dbg = nullptr;
     a.seeds = net->seeds;
-    // several CUs per board group (net_mfma_kernel SPLIT): 5x5 up to 256 positions and 6x6 up to 128, 16-bit storage — tz_net_eval at the reference's batch
+    // several CUs per board group (net_mfma_kernel SPLIT): 5x5 up to 256 positions, 4x4 and 6x6 up to 128, 16-bit storage — tz_net_eval at the reference's batch
     // and searches of such widths (the reference's selfplay runs 128 games: selfplay/src/main.rs:37).  TZ_NET_SPLIT=0: one CU per group (A/B)
     a.xch = nullptr;
     a.xch_count = nullptr;
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
-    if (!split_off && ((net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS) || (net->n == 6 && max_positions <= 2 * NET_SPLIT_MAX_GROUPS)) &&
+    if (!split_off && ((net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS) || ((net->n == 6 || net->n == 4) && max_positions <= 2 * NET_SPLIT_MAX_GROUPS)) &&
         (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) {
         if (!net->xch) {   // first use; a search's first two steps run outside its graph capture, so this is never inside one
             TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 8 * NET_SPLIT_PLANE_BYTES));

@@ -474,7 +474,7 @@ def test_net_launch_forms_are_bit_identical():
     assert out.returncode == 0 and "BIT-IDENTICAL" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("n", [5, 6])
+@pytest.mark.parametrize("n", [4, 5, 6])
 def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle, n):
     """tz_net_eval on 5x5 at batches up to 256 (the reference's batch is 128, selfplay/src/main.rs:37) runs net_mfma_kernel's SPLIT form: four
     workgroups per group of one, two or four boards, each computing a quarter of every conv's output channels and handing its planes to the
@@ -488,7 +488,7 @@ def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle,
     A = require_gpu()
     from takzero_amd import weights as W
 
-    arch, wname = (A.ARCH_NET5, "ARCH_NET5") if n == 5 else (A.ARCH_NET6_SIMHASH, "ARCH_NET6_SIMHASH")   # 6x6: groups of one or two boards, up to 128 positions
+    arch, wname = {4: (A.ARCH_NET4_SIMHASH, "ARCH_NET4_SIMHASH"), 5: (A.ARCH_NET5, "ARCH_NET5"), 6: (A.ARCH_NET6_SIMHASH, "ARCH_NET6_SIMHASH")}[n]   # 4x4, 6x6: groups of one or two boards, up to 128 positions
     states = random_positions(oracle, O, n, 4, 512 if n == 5 else 200, 17, max_ply=30)
     arr = O.states_array(states)
     acts = [O.possible_moves(oracle, s) for s in states]

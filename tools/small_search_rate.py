@@ -12,7 +12,7 @@ from takzero_amd import weights as W
 
 n, games = int(sys.argv[1]), int(sys.argv[2])
 sims = int(sys.argv[3]) if len(sys.argv) > 3 else 400
-arch, wa = (A.ARCH_NET5, W.ARCH_NET5) if n == 5 else (A.ARCH_NET6_SIMHASH, W.ARCH_NET6_SIMHASH)
+arch, wa = {4: (A.ARCH_NET4_SIMHASH, W.ARCH_NET4_SIMHASH), 5: (A.ARCH_NET5, W.ARCH_NET5), 6: (A.ARCH_NET6_SIMHASH, W.ARCH_NET6_SIMHASH)}[n]
 net = A.Net(arch=arch).load_tensors(W.init_weights(wa, seed=123))
 m = A.BatchedMCTS(games, n, 4, agent=net)
 m.new_openings(np.arange(games) % 16)
