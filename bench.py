@@ -431,12 +431,26 @@ def main():
                 states = mcts.get_positions()
                 ch, info = mcts.root_children(), mcts.root_info()
                 acts = [ch["move_idx"][g, :info["n_children"][g]] for g in range(256)]
-                out["agent_surface"] = {"what": "tz_net_eval, PCIe and staging included; up to 256 positions run on four CUs per board group"}
+                out["agent_surface"] = {"what": "the C ABI call tz_net_eval (arrays packed once, as a C / Rust host holds them), PCIe and staging "
+                                                "included; up to 256 positions run on four CUs per board group"}
+
                 for b in (128, 1):
-                    net.policy_value_uncertainty(states[:b], acts[:b])
+                    st_b = A._states(states[:b])
+                    amax = max(1, max(len(a) for a in acts[:b]))
+                    idx, cnt = np.zeros((b, amax), np.uint16), np.zeros(b, np.int32)
+                    for i, a in enumerate(acts[:b]):
+                        cnt[i] = len(a)
+                        idx[i, :len(a)] = a
+                    logits, value, var = np.zeros((b, amax), np.float32), np.zeros(b, np.float32), np.zeros(b, np.float32)
+
+                    def call():
+                        A.check(net.lib.tz_net_eval(net.h, b, st_b.ctypes.data, idx.ctypes.data, cnt.ctypes.data, amax, logits.ctypes.data,
+                                                    value.ctypes.data, var.ctypes.data))
+
+                    call()
                     t0 = time.perf_counter()
                     for _ in range(40):
-                        net.policy_value_uncertainty(states[:b], acts[:b])
+                        call()
                     per = (time.perf_counter() - t0) / 40
                     out["agent_surface"]["batch_%d" % b] = {"ms_per_call": 1000.0 * per, "positions_per_s": b / per}
             except Exception as e:

@@ -27,3 +27,19 @@ for B in (1, 8, 32, 128, 256, 512, 1024, 4096):
         net.policy_value_uncertainty(states[:B], acts[:B])
     dt = (time.perf_counter() - t0) / n
     print("tz_net_eval batch %d: %.2f ms per call, %.0f positions/s (host buffers in and out, PCIe included)" % (B, dt * 1e3, B / dt))
+    # the same call without the Python wrapper's packing of the legal-move lists (what a C / Rust host pays): arrays built once
+    st = A._states(states[:B])
+    amax = max(1, max(len(a) for a in acts[:B]))
+    idx = np.zeros((B, amax), np.uint16)
+    cnt = np.zeros(B, np.int32)
+    for i, a in enumerate(acts[:B]):
+        cnt[i] = len(a)
+        idx[i, :len(a)] = a
+    logits, value, var = np.zeros((B, amax), np.float32), np.zeros(B, np.float32), np.zeros(B, np.float32)
+    call = lambda: A.check(net.lib.tz_net_eval(net.h, B, st.ctypes.data, idx.ctypes.data, cnt.ctypes.data, amax, logits.ctypes.data, value.ctypes.data, var.ctypes.data))
+    call()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call()
+    dt = (time.perf_counter() - t0) / n
+    print("    the C ABI call alone (arrays packed once): %.3f ms per call, %.0f positions/s" % (dt * 1e3, B / dt))
