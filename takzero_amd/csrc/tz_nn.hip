@@ -1069,6 +1069,68 @@ __device__ __forceinline__ void k_loop_256_deep(const unsigned char* lds, const 
     }
 }
 
+// ... and for the split precision (TZ_PREC_F16X2: hi / lo halves of both operands, three MFMAs per product, see k_loop_split): the
+// several-CU form of the arithmetic that holds the 1e-3 tolerance.  Same order per output as k_loop_split: wh xh into the main
+// accumulator, then wl xh and wh xl into the correction accumulator, k-step by k-step.
+template <int RT, int RNX, int PLANE, int PD = 6, int AD = 3, typename WL>
+__device__ __forceinline__ void k_loop_split_deep(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&accm)[RT][RNX],
+                                                  f32x4 (&accc)[RT][RNX], WL wl) {
+    typedef Elem<_Float16> E;
+    typedef f16x8 ex8;
+    constexpr int TAPS = 9, STEPS = TAPS * 8, RING = 8, ARING = 4, LO = 8 * PLANE;
+    static_assert(PD < RING && AD < ARING, "prefetch distances");
+    int tb[TAPS][RT];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; tap++)
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) tb[tap][rt] = tap_table[(tap * RT + rt) * 64 + lane];
+    ex8 bq[RING][RNX][2];
+#pragma unroll
+    for (int d = 0; d < PD; d++)
+#pragma unroll
+        for (int j = 0; j < RNX; j++) {
+            bq[d][j][0] = wl(d / 8, d % 8, j, 0);
+            bq[d][j][1] = wl(d / 8, d % 8, j, 1);
+        }
+    ex8 ah[ARING][RT], al[ARING][RT];
+#pragma unroll
+    for (int d = 0; d < AD; d++)
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            ah[d][rt] = *reinterpret_cast<const ex8*>(lds + tb[d / 8][rt] + (d % 8) * PLANE);
+            al[d][rt] = *reinterpret_cast<const ex8*>(lds + tb[d / 8][rt] + (d % 8) * PLANE + LO);
+        }
+#pragma unroll
+    for (int st = 0; st < STEPS; st++) {
+        if (st + PD < STEPS) {
+#pragma unroll
+            for (int j = 0; j < RNX; j++) {
+                bq[(st + PD) % RING][j][0] = wl((st + PD) / 8, (st + PD) % 8, j, 0);
+                bq[(st + PD) % RING][j][1] = wl((st + PD) / 8, (st + PD) % 8, j, 1);
+            }
+        }
+        if (st + AD < STEPS) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int off = tb[(st + AD) / 8][rt] + ((st + AD) % 8) * PLANE;
+                ah[(st + AD) % ARING][rt] = *reinterpret_cast<const ex8*>(lds + off);
+                al[(st + AD) % ARING][rt] = *reinterpret_cast<const ex8*>(lds + off + LO);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+            for (int j = 0; j < RNX; j++) accm[rt][j] = E::mfma(bq[st % RING][j][0], ah[st % ARING][rt], accm[rt][j]);
+#pragma unroll
+            for (int j = 0; j < RNX; j++) accc[rt][j] = E::mfma(bq[st % RING][j][1], ah[st % ARING][rt], accc[rt][j]);
+#pragma unroll
+            for (int j = 0; j < RNX; j++) accc[rt][j] = E::mfma(bq[st % RING][j][0], al[st % ARING][rt], accc[rt][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row order of the LDS image.  A 3x3 tap whose source square is off the board multiplies a zero row: on 5x5 that is 56 of
 // the 225 (square, tap) pairs.  An MFMA covers 16 rows, so the zeros can only be skipped 16 rows at a time: with PERM the
@@ -1813,8 +1875,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     typedef typename Elem<ET>::x4 ex4;
     static_assert(!SP || sizeof(ET) == 2, "split precision runs on fp16 halves");
     constexpr int RN = 16 / (NW * SPLIT), TAPS = 9, LAYOUT = 1, NT = NW * 64;
-    static_assert((NW == 8 || NW == 4) && (NW == 8 || SP == 0), "four waves: the fp16 / bf16 form only");
-    static_assert(SPLIT == 1 || ((SPLIT == 2 || SPLIT == 4) && NW == 4 && SP == 0 && TT == 0 && ABL == 0), "several CUs per board group: the four-wave fp16 / bf16 form");
+    static_assert((NW == 8 || NW == 4) && (NW == 8 || SP != 2), "four waves: not the FP8-correction form");
+    static_assert(SPLIT == 1 || ((SPLIT == 2 || SPLIT == 4) && NW == 4 && SP != 2 && TT == 0 && ABL == 0 && !PERM), "several CUs per board group: the four-wave fp16 / bf16 / hi-lo forms, board-major rows");
     typedef RowMap<NB, P, PERM> RM;
     constexpr int NN = NB * NB, ROWS = P * NN, RT = RM::RT, LROWS = RT * 16 + 8, ZROW = RT * 16;
     constexpr int PLANE = LROWS * LDS_ROWB;
@@ -1941,11 +2003,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     int xround = 0;
     auto exchange = [&]() {
         if constexpr (SPLIT > 1) {
-            constexpr int MYPL = 8 / SPLIT, PL16 = PLANE / 16;
+            constexpr int MYPL = 8 / SPLIT, PL16 = PLANE / 16, HALVES = SP ? 2 : 1;   // split precision: the hi planes 0..7 and the lo planes 8..15
             __syncthreads();   // the member's own planes are complete in LDS
-            unsigned char* gbase = a.xch + (size_t)(group * 2 + (xround & 1)) * 8 * PLANE;
-            for (int i = tid; i < MYPL * PL16; i += NT) {
-                const int off = (member * MYPL + i / PL16) * PLANE + (i % PL16) * 16;
+            unsigned char* gbase = a.xch + (size_t)(group * 2 + (xround & 1)) * 8 * HALVES * PLANE;
+            for (int i = tid; i < HALVES * MYPL * PL16; i += NT) {
+                const int pl = i / PL16, off = ((pl / MYPL) * 8 + member * MYPL + pl % MYPL) * PLANE + (i % PL16) * 16;
                 *reinterpret_cast<uint4*>(gbase + off) = *reinterpret_cast<const uint4*>(lds + off);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged by the L2
@@ -1962,9 +2024,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 }
             }
             __syncthreads();
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, 8 * PLANE, 0x00020000);
-            for (int i = tid; i < (8 - MYPL) * PL16; i += NT) {
-                const int off = ((member * MYPL + MYPL + i / PL16) % 8) * PLANE + (i % PL16) * 16;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, 8 * HALVES * PLANE, 0x00020000);
+            for (int i = tid; i < HALVES * (8 - MYPL) * PL16; i += NT) {
+                const int pl = i / PL16, off = ((pl / (8 - MYPL)) * 8 + (member * MYPL + MYPL + pl % (8 - MYPL)) % 8) * PLANE + (i % PL16) * 16;
                 *reinterpret_cast<u32x4*>(lds + off) = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 17);
             }
             xround++;
@@ -2118,7 +2180,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
     constexpr int KPD = SPLIT > 1 ? 12 : P <= 2 ? 6 : 2;
     ex8 wpre[SPLIT > 1 ? KPD : 1][RN];
     auto preload_weights = [&](int layer) {
-        if constexpr (SPLIT > 1) {
+        if constexpr (SPLIT > 1 && SP == 0) {
 #pragma unroll
             for (int d = 0; d < KPD; d++)
 #pragma unroll
@@ -2173,7 +2235,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(part ? wrsrc_lo : wrsrc, lane16, frag * 1024, 0));
             };
-            k_loop_split<NB, P, PERM, RN, PLANE>(lds, tap_table, lane, acc, accc, wl2);
+            if constexpr (SPLIT > 1) k_loop_split_deep<RT, RN, PLANE>(lds, tap_table, lane, acc, accc, wl2);
+            else k_loop_split<NB, P, PERM, RN, PLANE>(lds, tap_table, lane, acc, accc, wl2);
         } else {
             auto wl = [&](int tap, int kc, int j) -> ex8 {
                 const int frag = layer * LAYER_FRAGS + (tap * 8 + kc) * 16 + (ct0 + j);
@@ -2394,7 +2457,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 const int frag = (tap * 8 + kc) * (8 * RNP) + (ctp + j);
                 return __builtin_bit_cast(ex8, __builtin_amdgcn_raw_buffer_load_b128(part ? rsl : rs, lane16, frag * 1024, 0));
             };
-            k_loop_split<NB, P, PERM, RNPW, PLANE>(lds, tap_table, lane, pacc, paccc, wlp2);
+            if constexpr (SPLIT > 1) k_loop_split_deep<RT, RNPW, PLANE>(lds, tap_table, lane, pacc, paccc, wlp2);
+            else k_loop_split<NB, P, PERM, RNPW, PLANE>(lds, tap_table, lane, pacc, paccc, wlp2);
 #pragma unroll
             for (int j = 0; j < RNPW; j++)
 #pragma unroll
@@ -3401,6 +3465,10 @@ int tz_nn_launch_split(int sp, int n, const void* net_args, int max_positions, h
     if (sp == 1) {
         // split precision: hi and lo planes share the 160 KB, so half the boards per workgroup (5x5: 4 boards, square-major
         // rows, 14 of 63 (tap, tile) pairs skipped; the other sizes board-major)
+        if (n == 5 && a.xch && max_positions <= 2 * NET_SPLIT_MAX_GROUPS) {   // up to 128 positions: four CUs per group of one or two boards
+            if (max_positions <= NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, _Float16, false, 1, 1, 0, 0, 4, 4>(a, max_positions, st);
+            return launch_net<5, 1, _Float16, false, 2, 1, 0, 0, 4, 4>(a, max_positions, st);
+        }
         switch (n) {
             case 3: return launch_net<3, 1, _Float16, false, 8, 1>(a, max_positions, st);
             case 4: return launch_net<4, 1, _Float16, false, 6, 1>(a, max_positions, st);
@@ -3546,10 +3614,12 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     a.xch = nullptr;
     a.xch_count = nullptr;
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
-    if (!split_off && ((net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS) || ((net->n == 6 || net->n == 4) && max_positions <= 2 * NET_SPLIT_MAX_GROUPS)) &&
-        (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) {
+    const bool split16 = (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
+                         ((net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS) || ((net->n == 6 || net->n == 4) && max_positions <= 2 * NET_SPLIT_MAX_GROUPS));
+    const bool splitx2 = net->precision == TZ_PREC_F16X2 && net->n == 5 && max_positions <= 2 * NET_SPLIT_MAX_GROUPS;   // the tolerance-holding arithmetic at the reference's batch
+    if (!split_off && (split16 || splitx2)) {
         if (!net->xch) {   // first use; a search's first two steps run outside its graph capture, so this is never inside one
-            TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 8 * NET_SPLIT_PLANE_BYTES));
+            TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 16 * NET_SPLIT_PLANE_BYTES));   // 16 planes: the hi / lo form
             TZ_HIP(hipMalloc((void**)&net->xch_count, (size_t)NET_SPLIT_MAX_GROUPS * 128));
         }
         a.xch = static_cast<unsigned char*>(net->xch);
@@ -4588,7 +4658,8 @@ int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* 
     NetOut o;
     // several CUs per board group for batches up to 128 on 5x5 in the 16-bit storage types (TZ_NET_SPLIT=0: one CU per group, A/B)
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
-    if (!split_off && net->n == 5 && batch <= NET_SPLIT_MAX_POSITIONS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
+    if (!split_off && net->n == 5 && ((batch <= NET_SPLIT_MAX_POSITIONS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) ||
+                                      (batch <= 2 * NET_SPLIT_MAX_GROUPS && net->precision == TZ_PREC_F16X2)) &&
         net->blocks > 0 && net_fused_mode() == 2) {
         if (!net->stream_rnd && !net->ev_in) {
             if (hipStreamCreateWithFlags(&net->stream_rnd, hipStreamNonBlocking) != hipSuccess ||
