@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void k_loop_256_deep(const unsigned char* lds, const 
 // ... and for the split precision (TZ_PREC_F16X2: hi / lo halves of both operands, three MFMAs per product, see k_loop_split): the
 // several-CU form of the arithmetic that holds the 1e-3 tolerance.  Same order per output as k_loop_split: wh xh into the main
 // accumulator, then wl xh and wh xl into the correction accumulator, k-step by k-step.
-template <int RT, int RNX, int PLANE, int PD = 6, int AD = 3, typename WL>
+template <int RT, int RNX, int PLANE, int PD = 6, int AD = (RT <= 4 ? 3 : 1), typename WL>
 __device__ __forceinline__ void k_loop_split_deep(const unsigned char* lds, const int* tap_table, int lane, f32x4 (&accm)[RT][RNX],
                                                   f32x4 (&accc)[RT][RNX], WL wl) {
     typedef Elem<_Float16> E;
@@ -3465,9 +3465,10 @@ int tz_nn_launch_split(int sp, int n, const void* net_args, int max_positions, h
     if (sp == 1) {
         // split precision: hi and lo planes share the 160 KB, so half the boards per workgroup (5x5: 4 boards, square-major
         // rows, 14 of 63 (tap, tile) pairs skipped; the other sizes board-major)
-        if (n == 5 && a.xch && max_positions <= 2 * NET_SPLIT_MAX_GROUPS) {   // up to 128 positions: four CUs per group of one or two boards
+        if (n == 5 && a.xch && max_positions <= NET_SPLIT_MAX_POSITIONS) {   // up to 256 positions: four CUs per group of one, two or four boards
             if (max_positions <= NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, _Float16, false, 1, 1, 0, 0, 4, 4>(a, max_positions, st);
-            return launch_net<5, 1, _Float16, false, 2, 1, 0, 0, 4, 4>(a, max_positions, st);
+            if (max_positions <= 2 * NET_SPLIT_MAX_GROUPS) return launch_net<5, 1, _Float16, false, 2, 1, 0, 0, 4, 4>(a, max_positions, st);
+            return launch_net<5, 1, _Float16, false, 4, 1, 0, 0, 4, 4>(a, max_positions, st);
         }
         switch (n) {
             case 3: return launch_net<3, 1, _Float16, false, 8, 1>(a, max_positions, st);
@@ -3616,7 +3617,7 @@ int net_fused(tz_net* net, const tz_state* states, const int32_t* gidx, const in
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
     const bool split16 = (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16) &&
                          ((net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS) || ((net->n == 6 || net->n == 4) && max_positions <= 2 * NET_SPLIT_MAX_GROUPS));
-    const bool splitx2 = net->precision == TZ_PREC_F16X2 && net->n == 5 && max_positions <= 2 * NET_SPLIT_MAX_GROUPS;   // the tolerance-holding arithmetic at the reference's batch
+    const bool splitx2 = net->precision == TZ_PREC_F16X2 && net->n == 5 && max_positions <= NET_SPLIT_MAX_POSITIONS;   // the tolerance-holding arithmetic at the reference's batch
     if (!split_off && (split16 || splitx2)) {
         if (!net->xch) {   // first use; a search's first two steps run outside its graph capture, so this is never inside one
             TZ_HIP(hipMalloc(&net->xch, (size_t)NET_SPLIT_MAX_GROUPS * 2 * 16 * NET_SPLIT_PLANE_BYTES));   // 16 planes: the hi / lo form
@@ -4659,7 +4660,7 @@ int tz_net_eval(tz_net* net, int batch, const tz_state* states, const uint16_t* 
     // several CUs per board group for batches up to 128 on 5x5 in the 16-bit storage types (TZ_NET_SPLIT=0: one CU per group, A/B)
     static const bool split_off = getenv("TZ_NET_SPLIT") && !strcmp(getenv("TZ_NET_SPLIT"), "0");
     if (!split_off && net->n == 5 && ((batch <= NET_SPLIT_MAX_POSITIONS && (net->precision == TZ_PREC_F16 || net->precision == TZ_PREC_BF16)) ||
-                                      (batch <= 2 * NET_SPLIT_MAX_GROUPS && net->precision == TZ_PREC_F16X2)) &&
+                                      (batch <= NET_SPLIT_MAX_POSITIONS && net->precision == TZ_PREC_F16X2)) &&
         net->blocks > 0 && net_fused_mode() == 2) {
         if (!net->stream_rnd && !net->ev_in) {
             if (hipStreamCreateWithFlags(&net->stream_rnd, hipStreamNonBlocking) != hipSuccess ||

@@ -505,7 +505,7 @@ def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle,
 
     with tempfile.TemporaryDirectory() as d:
         np.savez(os.path.join(d, "in.npz"), arr=np.frombuffer(arr.tobytes(), np.uint8), acts=np.array(acts, dtype=object))
-        # 5x5 also in the hi / lo split precision (TZ_PREC_F16X2, the arithmetic that holds the 1e-3 tolerance on trained nets): up to 128 positions
+        # 5x5 also in the hi / lo split precision (TZ_PREC_F16X2, the arithmetic that holds the 1e-3 tolerance on trained nets)
         for prec in (A.PREC_F16, A.PREC_BF16) + ((A.PREC_F16X2,) if n == 5 else ()):
             r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "in.npz"), str(prec), os.path.join(d, "off.npz")],
                                env=dict(os.environ, TZ_NET_SPLIT="0"), capture_output=True, text=True, timeout=600)
