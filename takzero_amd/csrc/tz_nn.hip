@@ -1863,12 +1863,13 @@ __device__ __forceinline__ void split_halves(float v, _Float16& hi, _Float16& lo
 // 16 / (4 SPLIT) column tiles) from the whole image, which every member holds; after a layer the members hand each other their planes
 // (a member's channels are 8 / SPLIT whole planes of the image) through a buffer in global memory.  For the Agent surface at the
 // reference's batch of 128, where one workgroup per board streams all 47 MB of weights through one CU's L1 (0.45 ms): with four
-// CUs each streams a quarter.  The hand-over is done by hand inside one XCD — plain stores, s_waitcnt vmcnt(0), an atomic that
-// the L2 executes, loads that bypass the L1: 1.4-1.9 us per layer (tools/cu_exchange_probe.hip) — because agent-scope release /
-// acquire writes back and invalidates the L2 on gfx950 (23-68 us per layer).  It rests on blocks b, b + 8, b + 16 .. being
-// dispatched to one XCD (round-robin over the 8 XCDs) and is used only where a wrong answer would show at once: tz_net_eval checks
-// the launch against the one-CU form in the tests, and a member that waits too long for its partners poisons its outputs with NaN
-// instead of hanging.  The accumulation order of an output does not depend on SPLIT (same k-loop, other RN): same bits as every other form.
+// CUs each streams a quarter.  The hand-over is written access by access — stores with sc0 sc1 (written through the L2), s_waitcnt
+// vmcnt(0), a system-scope atomic without a fence, loads with sc0 sc1 (past the L1 and any stale L2 line): 1.9-3.4 us per layer
+// whether the members share an XCD or not (tools/cu_exchange_probe.hip: no stale read in either placement) — because agent-scope
+// release / acquire fences write back and invalidate the whole L2 on gfx950 (23-68 us per layer).  Members are blocks b, b + 8,
+// b + 16, b + 24: one XCD under the dispatcher's round-robin, where the exchange is fastest (the L2 serves it), but nothing depends
+// on that.  A member that waits seconds for its partners poisons its outputs with NaN instead of hanging.  The accumulation order of
+// an output does not depend on SPLIT (same k-loop, other RN): same bits as every other form.
 template <int NB, int P, int RNP, typename ET, bool PERM = false, int SP = 0, int ABL = 0, int TT = 0, int NW = 8, int SPLIT = 1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetArgs a) {
     typedef typename Elem<ET>::x8 ex8;
@@ -2006,16 +2007,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
             constexpr int MYPL = 8 / SPLIT, PL16 = PLANE / 16, HALVES = SP ? 2 : 1;   // split precision: the hi planes 0..7 and the lo planes 8..15
             __syncthreads();   // the member's own planes are complete in LDS
             unsigned char* gbase = a.xch + (size_t)(group * 2 + (xround & 1)) * 8 * HALVES * PLANE;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, 8 * HALVES * PLANE, 0x00020000);
             for (int i = tid; i < HALVES * MYPL * PL16; i += NT) {
                 const int pl = i / PL16, off = ((pl / MYPL) * 8 + member * MYPL + pl % MYPL) * PLANE + (i % PL16) * 16;
-                *reinterpret_cast<uint4*>(gbase + off) = *reinterpret_cast<const uint4*>(lds + off);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(lds + off), rs, off, 0, 17);   // sc0 sc1: written through the L2
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged by the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged
             __syncthreads();
             if (tid == 0) {
                 unsigned* counter = a.xch_count + 32 * group;
                 const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(counter, 0, 128, 0x00020000);
-                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed by the L2
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // executed past the L2: no fence, the waitcnt above orders it
                 const unsigned want = (unsigned)SPLIT * (unsigned)(xround + 1);
                 int spins = 0;
                 while (!xch_failed && (unsigned)__builtin_amdgcn_raw_buffer_load_b32(crs, 0, 0, 17) < want) {   // sc0 sc1: past the L1
@@ -2024,7 +2026,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void net_mfma_kernel(NetA
                 }
             }
             __syncthreads();
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, 8 * HALVES * PLANE, 0x00020000);
             for (int i = tid; i < HALVES * (8 - MYPL) * PL16; i += NT) {
                 const int pl = i / PL16, off = ((pl / (8 - MYPL)) * 8 + (member * MYPL + MYPL + pl % (8 - MYPL)) % 8) * PLANE + (i % PL16) * 16;
                 *reinterpret_cast<u32x4*>(lds + off) = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 17);
