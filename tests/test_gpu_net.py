@@ -519,3 +519,36 @@ def test_agent_surface_with_four_cus_per_board_group_gives_the_same_bits(oracle,
                     assert np.array_equal(np.concatenate(l), off["l%d" % B]) and np.array_equal(v, off["v%d" % B]) and np.array_equal(u, off["u%d" % B]), (prec, B, rep)
                     assert all(np.array_equal(l[i], pol[i, np.asarray(acts[i], np.int64)]) for i in range(B)) and np.array_equal(v, val[:B])
             net.close()
+
+
+def test_two_processes_on_one_gpu_both_on_the_several_cu_form_write_the_same_bytes(tmp_path):
+    """The reference's deployment puts selfplay and reanalyze of 128 games each on one GPU (README.md:130).  At that width both run
+    the net kernel's several-CU form, whose members wait for each other inside the kernel: two such processes at once must neither
+    stall each other (a member whose partners are not resident yet waits; complete groups keep finishing and free their CUs) nor
+    change a result — each process writes, byte for byte, the targets and replays it writes when it has the GPU to itself."""
+    import subprocess
+    import sys
+
+    require_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import takzero_amd.api as A\n"
+            "from takzero_amd import selfplay as SP, weights as W\n"
+            "net = A.Net(arch=A.ARCH_NET5).load_tensors(W.init_weights(W.ARCH_NET5, seed=int(sys.argv[1])))\n"
+            "m = A.BatchedMCTS(128, 5, 4, agent=net, node_capacity=1 << 16)\n"
+            "sp = SP.NativeSelfPlay(m, 48, seed=int(sys.argv[1]), shard=0, search='puct')\n"
+            "for _ in range(25): sp.play_move()\n"
+            "open(sys.argv[2], 'wb').write(sp.take_text(0) + b'#' + sp.take_text(1))\n") % root
+    solo = []
+    for seed in (1, 2):
+        out = str(tmp_path / ("solo%d.bin" % seed))
+        r = subprocess.run([sys.executable, "-c", code, str(seed), out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        solo.append(open(out, "rb").read())
+    assert len(solo[0]) > 1000 and solo[0] != solo[1]
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(seed), str(tmp_path / ("pair%d.bin" % seed))], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for seed in (1, 2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1000:] for o in outs]
+    for seed, want in zip((1, 2), solo):
+        assert open(tmp_path / ("pair%d.bin" % seed), "rb").read() == want
